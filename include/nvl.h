@@ -1,0 +1,204 @@
+/*
+ * nvl.h — C ABI of libnvl_hip.so, the MI355X (gfx950) kernels behind the
+ * nano-vllm hot path (paged-KV forward step).
+ *
+ * Every entry point replaces one piece of arithmetic that the reference
+ * delegates to a third-party CUDA dependency (flash-attn, Triton, inductor).
+ * Citations are file:line in GeeeekExplorer/nano-vllm @ v0.2.0.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / HIP types in signatures
+ *     (`stream` is a hipStream_t passed as void*; NULL = the null stream).
+ *   - all pointers are DEVICE pointers unless a name ends in `_host`.
+ *   - bf16 activations / weights / KV cache, fp32 tables and temperatures,
+ *     int32 slots / context lengths / block tables / cu_seqlens,
+ *     int64 token ids / positions / sampled ids. 64-bit address arithmetic
+ *     everywhere (the reference's Triton store overflows int32 at 288 GB,
+ *     layers/attention.py:28).
+ *   - enqueue-only on `stream`: no allocation, no synchronisation, no host
+ *     callbacks => every call is hipGraph-capturable. The caller owns all
+ *     buffers including workspaces.
+ *   - return 0 on success, negative NVL_E* on error (arguments are validated
+ *     on the host before anything is launched); nvl_last_error() returns a
+ *     thread-local message. Nothing throws across the ABI.
+ *   - head_dim must be 128 (every Qwen3 size; models/qwen3.py:36).
+ *
+ * Paged KV-cache layout (ours; the reference's token-major
+ * [nblk, block, Hkv, D] of engine/model_runner.py:115 is never exposed to
+ * callers): per layer, K and V each are
+ *        [num_blocks][num_kv_heads][block_size][128] bf16
+ * i.e. head-major inside a block, so one (block, kv-head) tile is one
+ * contiguous block_size*256-byte run. slot = block*block_size + offset, as in
+ * the reference (engine/model_runner.py:151-161,181).
+ */
+#ifndef NVL_H_
+#define NVL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NVL_OK 0
+#define NVL_EINVAL (-1)   /* bad argument (message in nvl_last_error) */
+#define NVL_ELAUNCH (-2)  /* HIP launch error */
+#define NVL_EUNSUPPORTED (-3)
+
+/* ABI version: bumped on any signature change. */
+int nvl_abi_version(void);
+/* Thread-local description of the last error returned on this thread. */
+const char* nvl_last_error(void);
+/* Number of compute units of the current device (sizing persistent grids). */
+int nvl_device_cu_count(void);
+
+/* ---- RMSNorm ---------------------------------------------------------
+ * Replaces RMSNorm.rms_forward (layers/layernorm.py:16-26, inductor).
+ *   y = bf16( float(x) * rsqrt(mean(float(x)^2) + eps) * float(w) )
+ * (single rounding: what the reference's @torch.compile'd graph computes).
+ * Rows are addressed as (outer, inner): x row = x + outer*x_outer_stride +
+ * inner*hidden, y likewise; this covers both [N, hidden] and the strided
+ * q/k head views [N, H, 128] of models/qwen3.py:79-84. Strides in elements. */
+int nvl_rmsnorm(const void* x, int64_t x_outer_stride,
+                const void* weight,
+                void* y, int64_t y_outer_stride,
+                int64_t n_outer, int n_inner, int hidden, float eps,
+                void* stream);
+
+/* Replaces RMSNorm.add_rms_forward (layers/layernorm.py:28-40).
+ *   s = float(x) + float(residual); residual <- bf16(s);
+ *   y = bf16( s * rsqrt(mean(s^2)+eps) * float(w) )   (norm uses un-rounded s)
+ * x, residual, y: contiguous [rows, hidden]; residual is updated in place;
+ * y may alias x. */
+int nvl_add_rmsnorm(const void* x, void* residual, const void* weight, void* y,
+                    int64_t rows, int hidden, float eps, void* stream);
+
+/* ---- SiLU * mul ---------------------------------------------------------
+ * Replaces SiluAndMul.forward (layers/activation.py:8-11).
+ *   y[r, i] = bf16( silu(float(x[r, i])) * float(x[r, inter + i]) )
+ * x: [rows, 2*inter] with row stride x_row_stride; y: contiguous [rows, inter]. */
+int nvl_silu_mul(const void* x, int64_t x_row_stride, void* y,
+                 int64_t rows, int inter, void* stream);
+
+/* ---- Rotary embedding -----------------------------------------------------
+ * Replaces RotaryEmbedding.forward / apply_rotary_emb
+ * (layers/rotary_embedding.py:6-14, 37-48): neox (half-split) rotation from a
+ * fp32 table cos_sin[max_pos][128] = cos(64) || sin(64), fp32 math, one
+ * rounding to bf16. x: [n_tok, n_heads, 128] with token stride x_tok_stride
+ * (head stride 128); out: same shape, token stride out_tok_stride. */
+int nvl_rope_neox(const int64_t* positions, const float* cos_sin, int64_t max_pos,
+                  const void* x, int64_t x_tok_stride,
+                  void* out, int64_t out_tok_stride,
+                  int64_t n_tok, int n_heads, void* stream);
+
+/* ---- KV-cache store ---------------------------------------------------------
+ * Replaces store_kvcache_kernel / store_kvcache (layers/attention.py:10-40,
+ * Triton). k, v: [n_tok, Hkv, 128] with token strides (v is a strided view of
+ * the qkv GEMM output in the reference); slot_mapping[i] == -1 skips token i
+ * (layers/attention.py:23). Caches in the layout described at the top. */
+int nvl_store_kvcache(const void* k, int64_t k_tok_stride,
+                      const void* v, int64_t v_tok_stride,
+                      void* k_cache, void* v_cache,
+                      const int32_t* slot_mapping,
+                      int64_t n_tok, int num_kv_heads, int block_size,
+                      int64_t num_blocks, void* stream);
+
+/* ---- Fused q/k-RMSNorm -> RoPE -> KV-cache store ("KF") -------------------
+ * One launch for the four reference launches of models/qwen3.py:83-85 +
+ * layers/attention.py:63:   q = rope(q_norm(q)); k = rope(k_norm(k));
+ * store(k, v). Numerics identical to running nvl_rmsnorm, nvl_rope_neox and
+ * nvl_store_kvcache separately: q/k are rounded to bf16 after the norm and
+ * again after the rotation (they are separate compiled graphs in the
+ * reference). qkv: [n_tok, (Hq + 2*Hkv)*128] (q | k | v), token stride
+ * qkv_tok_stride. q_norm_w / k_norm_w may both be NULL (no q/k norm: the
+ * reference skips it when attention_bias is set, models/qwen3.py:68-70,82).
+ * q_out: contiguous [n_tok, Hq, 128] (required). k_out: optional contiguous
+ * [n_tok, Hkv, 128] (rotated keys, for the non-paged prefill path), may be
+ * NULL. k_cache/v_cache may be NULL (warm-up: no cache yet,
+ * layers/attention.py:62), then slot_mapping is ignored. */
+int nvl_qknorm_rope_kvstore(const void* qkv, int64_t qkv_tok_stride,
+                            const int64_t* positions,
+                            const void* q_norm_w, const void* k_norm_w, float eps,
+                            const float* cos_sin, int64_t max_pos,
+                            const int32_t* slot_mapping,
+                            void* q_out, void* k_out,
+                            void* k_cache, void* v_cache,
+                            int64_t n_tok, int num_q_heads, int num_kv_heads,
+                            int block_size, int64_t num_blocks, void* stream);
+
+/* ---- Paged decode attention ------------------------------------------------
+ * Replaces flash_attn_with_kvcache as called at layers/attention.py:72-74:
+ * single-query attention of q[b] over the first context_lens[b] tokens of the
+ * paged cache, GQA (kv_head = q_head / (Hq/Hkv)), fp32 scores/softmax,
+ * P rounded to bf16 before P.V, bf16 output. Rows with context_lens[b] == 0
+ * (graph padding, engine/model_runner.py:208) produce zeros.
+ * q: [batch, Hq, 128] contiguous; out: [batch, Hq, 128] contiguous.
+ * block_tables: [batch, bt_stride] int32, entries past the context unused
+ * (-1 padded, engine/model_runner.py:125). HBM-bound: reads
+ * context_len * 2 * Hkv * 256 bytes per sequence.
+ * Workspace holds split-KV partials; size from the _workspace_bytes query
+ * (depends on max_context, not on the per-step lengths => graph-safe). */
+size_t nvl_paged_attn_decode_workspace_bytes(int64_t max_batch, int num_q_heads,
+                                             int64_t max_context);
+int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
+                          const int32_t* block_tables, int64_t bt_stride,
+                          const int32_t* context_lens,
+                          void* out,
+                          int64_t batch, int num_q_heads, int num_kv_heads,
+                          int block_size, int64_t num_blocks, int64_t max_context,
+                          float softmax_scale,
+                          void* workspace, size_t workspace_bytes,
+                          void* stream);
+
+/* ---- Varlen causal prefill attention (MFMA) ----------------------------------
+ * Replaces flash_attn_varlen_func as called at layers/attention.py:67-70:
+ * packed variable-length causal attention, mask bottom-right aligned (query i
+ * of Lq sees keys j <= i + Lk - Lq), GQA, fp32 softmax, bf16 P, bf16 out.
+ * q: [sum Lq, Hq, 128] contiguous; out likewise.
+ * K/V source, exactly as the reference chooses it (layers/attention.py:65-66):
+ *   block_tables == NULL : k, v are packed [sum Lk, Hkv, 128] with token
+ *                          strides k_tok_stride / v_tok_stride;
+ *   block_tables != NULL : k, v are the paged caches (layout at the top),
+ *                          block_tables [num_seqs, bt_stride] (prefix cache /
+ *                          chunked prefill continuation).
+ * cu_seqlens_q / cu_seqlens_k: int32 [num_seqs + 1] (device). */
+int nvl_attn_prefill_varlen(const void* q, const void* k, const void* v,
+                            int64_t k_tok_stride, int64_t v_tok_stride,
+                            const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
+                            const int32_t* block_tables, int64_t bt_stride,
+                            void* out,
+                            int64_t total_q, int num_seqs, int max_seqlen_q,
+                            int num_q_heads, int num_kv_heads,
+                            int block_size, int64_t num_blocks,
+                            float softmax_scale, void* stream);
+
+/* ---- Token sampler ---------------------------------------------------------
+ * Replaces Sampler.forward (layers/sampler.py:7-12):
+ *   argmax_i softmax(l/T)_i / E_i,  E_i ~ Exp(1) clamped >= 1e-10
+ * computed in one pass as argmax_i (l_i/T - log E_i) (the softmax normaliser
+ * cancels), E_i from a counter-based Philox4x32-10 keyed by
+ * (seed, offset, row, column) so the draw is independent of the launch shape.
+ * Extension over the reference (sampling_params.py:11 forbids it):
+ * temperature == 0 => plain argmax, lowest index on ties.
+ * logits: [batch, vocab] bf16, row stride logits_row_stride; temperatures fp32
+ * [batch]; out int64 [batch]. `offset_dev` (optional, may be NULL) is a device
+ * uint64 added to `offset`, so a captured graph can advance the stream.
+ * workspace: nvl_sample_workspace_bytes(batch). */
+size_t nvl_sample_workspace_bytes(int64_t max_batch);
+int nvl_sample(const void* logits, int64_t logits_row_stride,
+               const float* temperatures, int64_t* out,
+               int64_t batch, int64_t vocab,
+               uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Host-side reference of the sampler's RNG (same Philox stream as the
+ * kernel): fills e[n] with the Exp(1) draws for columns [col0, col0+n) of
+ * `row`. Lets tests replay a GPU draw bit-exactly on the CPU. */
+void nvl_sample_exponentials_host(uint64_t seed, uint64_t offset, int64_t row,
+                                  int64_t col0, int64_t n, float* e_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NVL_H_ */

@@ -1,0 +1,92 @@
+"""Build libnvl_hip.so (the C-ABI HIP kernel library) for gfx950 with hipcc.
+
+In-tree build: the .so lands in nano_vllm_amd/lib/ (git-ignored, shipped by gpurun).
+hipcc cross-compiles without a GPU, so this also runs in the CPU-only build container.
+
+    python -m nano_vllm_amd.build [--force] [--verbose]
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libnvl_hip.so")
+STAMP = os.path.join(LIBDIR, "libnvl_hip.stamp")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
+
+
+def sources() -> list[str]:
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    files.append(os.path.join(HERE, "..", "include", "nvl.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def is_fresh() -> bool:
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as fh:
+        return fh.read().strip() == _digest()
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile every csrc/*.hip for gfx950 into one shared library; returns its path."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    if not force and is_fresh():
+        return LIB
+    hipcc = _hipcc()
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-c", src, "-o", obj]
+        if verbose:
+            cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            print(" ".join(cmd), flush=True)
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        objs.append(obj)
+    failed = False
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write(f"--- hipcc failed on {src}\n{out}\n")
+        elif verbose or out.strip():
+            sys.stderr.write(out)
+    if failed:
+        raise RuntimeError("hipcc compilation failed")
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
+    subprocess.run(cmd, check=True)
+    for o in objs:
+        os.remove(o)
+    with open(STAMP, "w") as fh:
+        fh.write(_digest())
+    return LIB
+
+
+if __name__ == "__main__":
+    path = build(force="--force" in sys.argv, verbose="--verbose" in sys.argv)
+    print(path)

@@ -1,0 +1,106 @@
+// Shared device/host helpers for the gfx950 kernels of libnvl_hip.so.
+// CDNA4 only: 64-wide wavefronts are hard-coded (no dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/nvl.h"
+
+#define NVL_WAVE 64
+#define NVL_HEAD_DIM 128
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// ---- host-side error plumbing -------------------------------------------------
+void nvl_set_error(const char* fmt, ...);
+int nvl_check_launch(const char* what);
+
+#define NVL_REQUIRE(cond, ...)            \
+  do {                                    \
+    if (!(cond)) {                        \
+      nvl_set_error(__VA_ARGS__);         \
+      return NVL_EINVAL;                  \
+    }                                     \
+  } while (0)
+
+// ---- bf16 <-> fp32 ------------------------------------------------------------
+// A 32-bit word holds two bf16: element 0 in the low half.
+__device__ __forceinline__ float bf16lo_to_f32(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+
+// Round-to-nearest-even fp32 -> bf16 (the compiler emits v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+  bf16x2_t v;
+  v[0] = (bf16_t)lo;
+  v[1] = (bf16_t)hi;
+  return __builtin_bit_cast(unsigned int, v);
+}
+__device__ __forceinline__ float round_bf16(float x) { return (float)(bf16_t)x; }
+
+__device__ __forceinline__ void unpack8(const u32x4_t& w, float* f) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f[2 * i] = bf16lo_to_f32(w[i]);
+    f[2 * i + 1] = bf16hi_to_f32(w[i]);
+  }
+}
+__device__ __forceinline__ u32x4_t pack8(const float* f) {
+  u32x4_t w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) w[i] = pack_bf16x2(f[2 * i], f[2 * i + 1]);
+  return w;
+}
+
+// ---- cross-lane -----------------------------------------------------------------
+// Sum over the 16 lanes of a DPP row (lanes 16r..16r+15); every lane gets the total.
+__device__ __forceinline__ float row16_allreduce_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+// Value held by the lane 8 positions away inside the same 16-lane row.
+__device__ __forceinline__ float row16_ror8(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_allreduce_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_allreduce_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ---- Philox4x32-10 (host + device, identical) -------------------------------------
+struct Philox4 {
+  uint32_t v[4];
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                          uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    uint64_t p0 = (uint64_t)M0 * c0;
+    uint64_t p1 = (uint64_t)M1 * c2;
+    uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    uint32_t n0 = hi1 ^ c1 ^ k0;
+    uint32_t n2 = hi0 ^ c3 ^ k1;
+    c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+    k0 += W0; k1 += W1;
+  }
+  Philox4 o;
+  o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+  return o;
+}

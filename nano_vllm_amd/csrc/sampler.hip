@@ -1,0 +1,157 @@
+// Single-pass token sampler for gfx950.
+// Replaces Sampler.forward (nano-vllm layers/sampler.py:7-12):
+//     argmax_i softmax(l/T)_i / E_i ,  E_i ~ Exp(1), clamp_min 1e-10
+// = argmax_i ( l_i/T - log E_i )  — the softmax normaliser is common to the row and cancels,
+// so one streaming read of the bf16 logits (2 B/logit) replaces the reference's fp32 [B,V]
+// temporaries. E_i comes from Philox4x32-10 keyed by (seed; offset, row, column/4): the draw
+// does not depend on grid shape, so host code can replay it (nvl_sample_exponentials_host).
+// T == 0 selects plain argmax (lowest index wins ties), an extension the reference forbids
+// (sampling_params.py:11) but the parity harness needs.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int kSplits = 8;  // workgroups per row
+
+// u in (0,1): 24 random bits, centred.
+__host__ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+__host__ __device__ __forceinline__ float exp1_from_bits(uint32_t x) {
+#ifdef __HIP_DEVICE_COMPILE__
+  const float e = -__logf(u01(x));
+#else
+  const float e = -logf(u01(x));
+#endif
+  return e < 1e-10f ? 1e-10f : e;
+}
+
+struct Best {
+  float v;
+  int idx;
+};
+__device__ __forceinline__ Best better(Best a, Best b) {
+  // larger value wins; on ties the lower index (torch.argmax: first maximal value)
+  if (b.v > a.v || (b.v == a.v && b.idx < a.idx)) return b;
+  return a;
+}
+
+__global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __restrict__ logits, int64_t row_stride,
+                                                              const float* __restrict__ temps, int64_t vocab,
+                                                              uint64_t seed, uint64_t offset,
+                                                              const uint64_t* __restrict__ offset_dev,
+                                                              float* __restrict__ ws_val, int* __restrict__ ws_idx) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int64_t row = blockIdx.y;
+  const int split = blockIdx.x;
+  const float T = temps[row];
+  const bool greedy = !(T > 0.f);
+  const float invT = greedy ? 1.f : 1.f / T;
+  const uint64_t off = offset + (offset_dev ? *offset_dev : 0ull);
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  const bf16_t* lr = logits + row * row_stride;
+  const int64_t nchunks = (vocab + 7) >> 3;
+  const int64_t per = (nchunks + kSplits - 1) / kSplits;
+  const int64_t c_begin = split * per;
+  const int64_t c_end = min(nchunks, c_begin + per);
+  Best best{-INFINITY, 0x7fffffff};
+  const bool vec_ok = ((reinterpret_cast<uintptr_t>(lr) & 15) == 0);
+  for (int64_t c = c_begin + threadIdx.x; c < c_end; c += 256) {
+    const int64_t col0 = c * 8;
+    float f[8];
+    if (vec_ok && col0 + 8 <= vocab) {
+      unpack8(*reinterpret_cast<const u32x4_t*>(lr + col0), f);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) f[i] = (col0 + i < vocab) ? (float)lr[col0 + i] : -INFINITY;
+    }
+    float key[8];
+    if (greedy) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) key[i] = f[i];
+    } else {
+      const Philox4 r0 = philox4x32_10((uint32_t)(2 * c), (uint32_t)((2 * c) >> 32) ^ (uint32_t)(off << 8), (uint32_t)row,
+                                       (uint32_t)(off >> 24), k0, k1);
+      const Philox4 r1 = philox4x32_10((uint32_t)(2 * c + 1), (uint32_t)((2 * c + 1) >> 32) ^ (uint32_t)(off << 8),
+                                       (uint32_t)row, (uint32_t)(off >> 24), k0, k1);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const uint32_t bits = i < 4 ? r0.v[i] : r1.v[i - 4];
+        key[i] = f[i] * invT - __logf(exp1_from_bits(bits));
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (col0 + i < vocab) best = better(best, Best{key[i], (int)(col0 + i)});
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Best other{__shfl_xor(best.v, o, 64), __shfl_xor(best.idx, o, 64)};
+    best = better(best, other);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    sv[wave] = best.v;
+    si[wave] = best.idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Best b{sv[0], si[0]};
+#pragma unroll
+    for (int w = 1; w < 4; ++w) b = better(b, Best{sv[w], si[w]});
+    ws_val[row * kSplits + split] = b.v;
+    ws_idx[row * kSplits + split] = b.idx;
+  }
+}
+
+__global__ __launch_bounds__(64) void sample_final_kernel(const float* __restrict__ ws_val,
+                                                           const int* __restrict__ ws_idx, int64_t* __restrict__ out,
+                                                           int64_t batch) {
+  const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (row >= batch) return;
+  Best b{ws_val[row * kSplits], ws_idx[row * kSplits]};
+#pragma unroll
+  for (int s = 1; s < kSplits; ++s) b = better(b, Best{ws_val[row * kSplits + s], ws_idx[row * kSplits + s]});
+  out[row] = b.idx == 0x7fffffff ? 0 : (int64_t)b.idx;
+}
+
+}  // namespace
+
+extern "C" size_t nvl_sample_workspace_bytes(int64_t max_batch) {
+  if (max_batch <= 0) return 0;
+  return (size_t)max_batch * kSplits * (sizeof(float) + sizeof(int));
+}
+
+extern "C" int nvl_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, int64_t* out,
+                          int64_t batch, int64_t vocab, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  NVL_REQUIRE(logits && temperatures && out && workspace, "nvl_sample: null pointer");
+  NVL_REQUIRE(batch >= 0 && batch <= 65535, "nvl_sample: batch=%lld out of range [0, 65535]", (long long)batch);
+  NVL_REQUIRE(vocab > 0 && vocab < (1ll << 31) - 8, "nvl_sample: bad vocab=%lld", (long long)vocab);
+  NVL_REQUIRE(logits_row_stride >= vocab, "nvl_sample: row stride < vocab");
+  NVL_REQUIRE(workspace_bytes >= nvl_sample_workspace_bytes(batch), "nvl_sample: workspace too small");
+  NVL_REQUIRE(((uintptr_t)workspace) % 8 == 0, "nvl_sample: workspace must be 8-byte aligned");
+  if (batch == 0) return NVL_OK;
+  float* ws_val = (float*)workspace;
+  int* ws_idx = (int*)(ws_val + (size_t)batch * kSplits);
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sample_partial_kernel, dim3(kSplits, (unsigned)batch), dim3(256), 0, s, (const bf16_t*)logits,
+                     logits_row_stride, temperatures, vocab, seed, offset, offset_dev, ws_val, ws_idx);
+  hipLaunchKernelGGL(sample_final_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, ws_val, ws_idx, out,
+                     batch);
+  return nvl_check_launch("nvl_sample");
+}
+
+extern "C" void nvl_sample_exponentials_host(uint64_t seed, uint64_t offset, int64_t row, int64_t col0, int64_t n,
+                                             float* e_host) {
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  for (int64_t j = 0; j < n; ++j) {
+    const int64_t col = col0 + j;
+    const int64_t ctr = col >> 2;  // one Philox call per 4 columns: call index = 2*(col/8) + (col%8)/4
+    const Philox4 r = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32) ^ (uint32_t)(offset << 8), (uint32_t)row,
+                                    (uint32_t)(offset >> 24), k0, k1);
+    e_host[j] = exp1_from_bits(r.v[col & 3]);
+  }
+}

@@ -1,0 +1,258 @@
+"""ctypes binding of libnvl_hip.so (C ABI in include/nvl.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every function below
+hands raw device pointers + sizes to a hand-written gfx950 kernel. There is NO fallback:
+if the library is missing or fails to load, importing callers get a loud RuntimeError.
+
+`import torch` must precede loading the library so that it binds to the HIP runtime torch
+already loaded (one runtime => shared streams, pointers and graph capture).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnvl_hip.so")
+ABI_VERSION = 1
+
+# name -> (restype, argtypes); mirrors include/nvl.h one to one (checked by tests/test_abi.py)
+SIGNATURES = {
+    "nvl_abi_version": (c_int, []),
+    "nvl_last_error": (c_char_p, []),
+    "nvl_device_cu_count": (c_int, []),
+    "nvl_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_void_p]),
+    "nvl_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "nvl_silu_mul": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "nvl_rope_neox": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "nvl_store_kvcache": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "nvl_qknorm_rope_kvstore": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
+                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                        c_int64, c_void_p]),
+    "nvl_paged_attn_decode_workspace_bytes": (c_size_t, [c_int64, c_int, c_int64]),
+    "nvl_paged_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
+                                      c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
+    "nvl_attn_prefill_varlen": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
+                                        c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
+                                        c_void_p]),
+    "nvl_sample_workspace_bytes": (c_size_t, [c_int64]),
+    "nvl_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_void_p,
+                           c_void_p, c_size_t, c_void_p]),
+    "nvl_sample_exponentials_host": (None, [c_uint64, c_uint64, c_int64, c_int64, c_int64, c_void_p]),
+}
+
+_lib = None
+
+
+class NvlError(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None) -> ctypes.CDLL:
+    """Load libnvl_hip.so and bind every symbol of the ABI. Raises if anything is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise NvlError(
+            f"{path} not found: build it with `python -m nano_vllm_amd.build` (hipcc, gfx950). "
+            "There is no CPU/PyTorch fallback for the hot path.")
+    lib = ctypes.CDLL(path)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError => ABI mismatch, fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    ver = lib.nvl_abi_version()
+    if ver != ABI_VERSION:
+        raise NvlError(f"libnvl_hip.so ABI version {ver} != binding version {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def lib() -> ctypes.CDLL:
+    return _lib if _lib is not None else load_library()
+
+
+def _check(rc: int) -> None:
+    if rc != 0:
+        raise NvlError(f"nvl error {rc}: {lib().nvl_last_error().decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise NvlError(f"{name} must be a device (HIP) tensor; the hot path has no CPU fallback")
+
+
+# ---------------------------------------------------------------------------------------------
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: torch.Tensor | None = None) -> torch.Tensor:
+    """y = bf16(float(x) * rsqrt(mean x^2 + eps) * float(w)); x is [..., hidden] or a strided
+    [N, H, 128] head view (stride(-1) == 1, stride(-2) == hidden when 3-D)."""
+    _dev(x, "x")
+    hidden = x.shape[-1]
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and x.stride(-1) == 1
+    if x.dim() == 3:
+        n_outer, n_inner = x.shape[0], x.shape[1]
+        assert x.stride(1) == hidden
+        xs = x.stride(0)
+    else:
+        assert x.dim() == 2
+        n_outer, n_inner, xs = x.shape[0], 1, x.stride(0)
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    ys = out.stride(0)
+    _check(lib().nvl_rmsnorm(x.data_ptr(), xs, weight.data_ptr(), out.data_ptr(), ys, n_outer, n_inner, hidden,
+                             eps, _stream()))
+    return out
+
+
+def add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                out: torch.Tensor | None = None) -> torch.Tensor:
+    """residual <- bf16(x + residual) in place; returns y = norm(un-rounded sum) * w."""
+    _dev(x, "x")
+    assert x.dim() == 2 and x.is_contiguous() and residual.is_contiguous() and x.shape == residual.shape
+    assert x.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty_like(x)
+    _check(lib().nvl_add_rmsnorm(x.data_ptr(), residual.data_ptr(), weight.data_ptr(), out.data_ptr(), x.shape[0],
+                                 x.shape[1], eps, _stream()))
+    return out
+
+
+def silu_mul(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    _dev(x, "x")
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.bfloat16
+    inter = x.shape[1] // 2
+    if out is None:
+        out = torch.empty((x.shape[0], inter), dtype=x.dtype, device=x.device)
+    _check(lib().nvl_silu_mul(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], inter, _stream()))
+    return out
+
+
+def rope_neox(positions: torch.Tensor, cos_sin: torch.Tensor, x: torch.Tensor,
+              out: torch.Tensor | None = None) -> torch.Tensor:
+    """x: [N, H, 128] (stride(1) == 128); cos_sin: fp32 [max_pos, 128]."""
+    _dev(x, "x")
+    assert x.dim() == 3 and x.shape[2] == 128 and x.stride(2) == 1 and x.stride(1) == 128
+    assert positions.dtype == torch.int64 and cos_sin.dtype == torch.float32 and cos_sin.is_contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=x.dtype, device=x.device)
+    _check(lib().nvl_rope_neox(positions.data_ptr(), cos_sin.data_ptr(), cos_sin.shape[0], x.data_ptr(), x.stride(0),
+                               out.data_ptr(), out.stride(0), x.shape[0], x.shape[1], _stream()))
+    return out
+
+
+def store_kvcache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                  slot_mapping: torch.Tensor) -> None:
+    """k, v: [N, Hkv, 128] (stride(1) == 128); caches: [num_blocks, Hkv, block_size, 128]."""
+    _dev(k, "k")
+    n, hkv, d = k.shape
+    assert d == 128 and k.stride(1) == 128 and v.stride(1) == 128 and k.stride(2) == 1 and v.stride(2) == 1
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and slot_mapping.dtype == torch.int32
+    assert slot_mapping.numel() == n
+    _check(lib().nvl_store_kvcache(k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), k_cache.data_ptr(),
+                                   v_cache.data_ptr(), slot_mapping.data_ptr(), n, hkv, k_cache.shape[2],
+                                   k_cache.shape[0], _stream()))
+
+
+def qknorm_rope_kvstore(qkv: torch.Tensor, positions: torch.Tensor, q_norm_w, k_norm_w, eps: float,
+                        cos_sin: torch.Tensor, slot_mapping, q_out: torch.Tensor, k_out, k_cache, v_cache,
+                        num_q_heads: int, num_kv_heads: int) -> None:
+    _dev(qkv, "qkv")
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.dtype == torch.bfloat16
+    has_cache = k_cache is not None and k_cache.numel() > 0
+    _check(lib().nvl_qknorm_rope_kvstore(
+        qkv.data_ptr(), qkv.stride(0), positions.data_ptr(),
+        q_norm_w.data_ptr() if q_norm_w is not None else None,
+        k_norm_w.data_ptr() if k_norm_w is not None else None, eps,
+        cos_sin.data_ptr(), cos_sin.shape[0],
+        slot_mapping.data_ptr() if (has_cache and slot_mapping is not None) else None,
+        q_out.data_ptr(), k_out.data_ptr() if k_out is not None else None,
+        k_cache.data_ptr() if has_cache else None, v_cache.data_ptr() if has_cache else None,
+        qkv.shape[0], num_q_heads, num_kv_heads,
+        k_cache.shape[2] if has_cache else 0, k_cache.shape[0] if has_cache else 0, _stream()))
+
+
+def paged_attn_decode_workspace_bytes(max_batch: int, num_q_heads: int, max_context: int) -> int:
+    return lib().nvl_paged_attn_decode_workspace_bytes(max_batch, num_q_heads, max_context)
+
+
+def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
+                      context_lens: torch.Tensor, scale: float, max_context: int, workspace: torch.Tensor,
+                      out: torch.Tensor | None = None) -> torch.Tensor:
+    """q: [B, Hq, 128]; caches [num_blocks, Hkv, block_size, 128]; block_tables int32 [B, W]."""
+    _dev(q, "q")
+    b, hq, d = q.shape
+    assert d == 128 and q.is_contiguous() and block_tables.dtype == torch.int32 and context_lens.dtype == torch.int32
+    assert block_tables.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(q)
+    _check(lib().nvl_paged_attn_decode(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
+                                       block_tables.stride(0), context_lens.data_ptr(), out.data_ptr(), b, hq,
+                                       k_cache.shape[1], k_cache.shape[2], k_cache.shape[0], max_context, scale,
+                                       workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+    return out
+
+
+def attn_prefill_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor,
+                        cu_seqlens_k: torch.Tensor, max_seqlen_q: int, scale: float,
+                        block_tables: torch.Tensor | None = None, num_kv_heads: int | None = None,
+                        out: torch.Tensor | None = None) -> torch.Tensor:
+    """q: [Nq, Hq, 128]. block_tables None: k, v packed [Nk, Hkv, 128] (token-strided views ok);
+    otherwise k, v are the paged caches [num_blocks, Hkv, block_size, 128]."""
+    _dev(q, "q")
+    nq, hq, d = q.shape
+    assert d == 128 and q.is_contiguous()
+    assert cu_seqlens_q.dtype == torch.int32 and cu_seqlens_k.dtype == torch.int32
+    if out is None:
+        out = torch.empty_like(q)
+    num_seqs = cu_seqlens_q.numel() - 1
+    if block_tables is None:
+        hkv = k.shape[1]
+        assert k.stride(1) == 128 and v.stride(1) == 128 and k.stride(2) == 1 and v.stride(2) == 1
+        _check(lib().nvl_attn_prefill_varlen(q.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0),
+                                             cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), None, 0,
+                                             out.data_ptr(), nq, num_seqs, max_seqlen_q, hq, hkv, 0, 0, scale,
+                                             _stream()))
+    else:
+        assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
+        _check(lib().nvl_attn_prefill_varlen(q.data_ptr(), k.data_ptr(), v.data_ptr(), 0, 0,
+                                             cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(),
+                                             block_tables.data_ptr(), block_tables.stride(0), out.data_ptr(), nq,
+                                             num_seqs, max_seqlen_q, hq, k.shape[1], k.shape[2], k.shape[0], scale,
+                                             _stream()))
+    return out
+
+
+def sample_workspace_bytes(max_batch: int) -> int:
+    return lib().nvl_sample_workspace_bytes(max_batch)
+
+
+def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: int, workspace: torch.Tensor,
+           out: torch.Tensor | None = None, offset_dev: torch.Tensor | None = None) -> torch.Tensor:
+    """logits bf16 [B, V]; temperatures fp32 [B] (0 => argmax); returns int64 [B]."""
+    _dev(logits, "logits")
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype == torch.bfloat16
+    assert temperatures.dtype == torch.float32
+    b, vocab = logits.shape
+    if out is None:
+        out = torch.empty(b, dtype=torch.int64, device=logits.device)
+    _check(lib().nvl_sample(logits.data_ptr(), logits.stride(0), temperatures.data_ptr(), out.data_ptr(), b, vocab,
+                            seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF,
+                            offset_dev.data_ptr() if offset_dev is not None else None, workspace.data_ptr(),
+                            workspace.numel() * workspace.element_size(), _stream()))
+    return out
+
+
+def sample_exponentials_host(seed: int, offset: int, row: int, col0: int, n: int):
+    import numpy as np
+    e = np.empty(n, dtype=np.float32)
+    lib().nvl_sample_exponentials_host(seed, offset, row, col0, n, e.ctypes.data_as(c_void_p))
+    return e

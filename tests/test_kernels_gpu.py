@@ -1,0 +1,323 @@
+"""Parity of every HIP kernel (called through the C ABI, nano_vllm_amd.ops -> libnvl_hip.so)
+against the CPU oracle (oracle/ops.py) on identical seeded inputs.
+
+Tolerances: pointwise ops <= 1 bf16 ulp vs the fp32 restatement that rounds where
+the compiled reference rounds (rotary and KV store are bit-exact); attention max-abs-diff
+<= 2e-2 * absmax (flash tolerance; P is rounded to bf16 before P.V in both).
+"""
+import math
+
+import pytest
+import torch
+
+from oracle import ops as ref
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from nano_vllm_amd import ops as _ops
+    _ops.load_library()
+    return _ops
+
+
+def dev(t):
+    return t.cuda()
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def max_ulp(a, b):
+    return int(ref.bf16_ulp_diff(a.cpu(), b.cpu()).max())
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,hidden", [(1, 1024), (131, 1024), (7, 4096), (33, 5120), (5, 2048), (3, 8192), (2, 64)])
+def test_rmsnorm(ops, rows, hidden):
+    x = (torch.randn(rows, hidden, generator=g(1)) * 3).to(BF16)
+    w = (1 + 0.1 * torch.randn(hidden, generator=g(2))).to(BF16)
+    y = ops.rmsnorm(dev(x), dev(w), 1e-6)
+    assert max_ulp(y, ref.rms_forward(x, w, 1e-6)) <= 1
+
+
+@pytest.mark.parametrize("n,h,hkv", [(1, 16, 8), (37, 16, 8), (130, 32, 8), (9, 8, 1)])
+def test_rmsnorm_head_view(ops, n, h, hkv):
+    """q/k-norm over strided views of the qkv GEMM output (models/qwen3.py:78-84)."""
+    qkv = torch.randn(n, (h + 2 * hkv) * 128, generator=g(3)).to(BF16)
+    w = (1 + 0.1 * torch.randn(128, generator=g(4))).to(BF16)
+    q = qkv[:, : h * 128].view(n, h, 128)
+    k = qkv[:, h * 128: (h + hkv) * 128].view(n, hkv, 128)
+    dq = dev(qkv)
+    yq = ops.rmsnorm(dq[:, : h * 128].view(n, h, 128), dev(w), 1e-6)
+    yk = ops.rmsnorm(dq[:, h * 128: (h + hkv) * 128].view(n, hkv, 128), dev(w), 1e-6)
+    assert max_ulp(yq, ref.rms_forward(q, w, 1e-6)) <= 1
+    assert max_ulp(yk, ref.rms_forward(k, w, 1e-6)) <= 1
+
+
+@pytest.mark.parametrize("rows,hidden", [(1, 1024), (131, 1024), (16, 4096), (9, 5120)])
+def test_add_rmsnorm(ops, rows, hidden):
+    x = torch.randn(rows, hidden, generator=g(5)).to(BF16)
+    r = (torch.randn(rows, hidden, generator=g(6)) * 2).to(BF16)
+    w = (1 + 0.1 * torch.randn(hidden, generator=g(7))).to(BF16)
+    y_ref, r_ref = ref.add_rms_forward(x, r, w, 1e-6)
+    dr = dev(r.clone())
+    y = ops.add_rmsnorm(dev(x), dr, dev(w), 1e-6)
+    assert torch.equal(dr.cpu(), r_ref)  # residual = bf16(x + r): exact
+    assert max_ulp(y, y_ref) <= 1
+
+
+@pytest.mark.parametrize("rows,inter", [(1, 3072), (131, 3072), (17, 12288), (5, 3200), (3, 8)])
+def test_silu_mul(ops, rows, inter):
+    x = (torch.randn(rows, 2 * inter, generator=g(8)) * 2).to(BF16)
+    y = ops.silu_mul(dev(x))
+    assert max_ulp(y, ref.silu_and_mul(x)) <= 1
+
+
+# ------------------------------------------------------------------------------------------
+def test_rope_bit_exact(ops):
+    n, h, hkv = 77, 16, 8
+    table = ref.rope_table(128, 4096, 1e6)
+    pos = torch.randint(0, 4096, (n,), generator=g(9))
+    q = torch.randn(n, h, 128, generator=g(10)).to(BF16)
+    k = torch.randn(n, hkv, 128, generator=g(11)).to(BF16)
+    q_ref, k_ref = ref.rotary_forward(pos, q, k, table)
+    dt, dp = dev(table), dev(pos)
+    assert torch.equal(ops.rope_neox(dp, dt, dev(q)).cpu(), q_ref)
+    assert torch.equal(ops.rope_neox(dp, dt, dev(k)).cpu(), k_ref)
+
+
+def test_store_kvcache_bit_exact(ops):
+    n, hkv, nblk, bs = 300, 8, 6, 256
+    k = torch.randn(n, hkv, 128, generator=g(12)).to(BF16)
+    qkv = torch.randn(n, 4096, generator=g(13)).to(BF16)
+    v = qkv[:, 3072:].view(n, hkv, 128)  # strided view, as in the reference
+    slots = torch.randperm(nblk * bs, generator=g(14))[:n].to(torch.int32)
+    slots[::7] = -1
+    kc_ref = torch.zeros(nblk, bs, hkv, 128, dtype=BF16)
+    vc_ref = torch.zeros_like(kc_ref)
+    ref.store_kvcache(k, v, kc_ref, vc_ref, slots)
+    kc = torch.zeros(nblk, hkv, bs, 128, dtype=BF16, device="cuda")
+    vc = torch.zeros_like(kc)
+    dqkv = dev(qkv)
+    ops.store_kvcache(dev(k), dqkv[:, 3072:].view(n, hkv, 128), kc, vc, dev(slots))
+    assert torch.equal(ref.from_head_major(kc.cpu()), kc_ref)
+    assert torch.equal(ref.from_head_major(vc.cpu()), vc_ref)
+
+
+@pytest.mark.parametrize("n,h,hkv", [(1, 16, 8), (131, 16, 8), (40, 32, 8), (19, 8, 1)])
+def test_fused_qknorm_rope_kvstore(ops, n, h, hkv):
+    nblk, bs = 4, 256
+    qkv = torch.randn(n, (h + 2 * hkv) * 128, generator=g(15)).to(BF16)
+    qw = (1 + 0.1 * torch.randn(128, generator=g(16))).to(BF16)
+    kw = (1 + 0.1 * torch.randn(128, generator=g(17))).to(BF16)
+    table = ref.rope_table(128, 2048, 1e6)
+    pos = torch.randint(0, 2048, (n,), generator=g(18))
+    slots = torch.randperm(nblk * bs, generator=g(19))[:n].to(torch.int32)
+    if n > 3:
+        slots[2] = -1
+    # oracle: the reference's four separate steps (models/qwen3.py:78-85, attention.py:63)
+    q, k, v = qkv.split([h * 128, hkv * 128, hkv * 128], dim=-1)
+    q = ref.rms_forward(q.reshape(n, h, 128), qw, 1e-6)
+    k = ref.rms_forward(k.reshape(n, hkv, 128), kw, 1e-6)
+    q_ref, k_ref = ref.rotary_forward(pos, q, k, table)
+    kc_ref = torch.zeros(nblk, bs, hkv, 128, dtype=BF16)
+    vc_ref = torch.zeros_like(kc_ref)
+    ref.store_kvcache(k_ref, v.reshape(n, hkv, 128), kc_ref, vc_ref, slots)
+
+    q_out = torch.empty(n, h, 128, dtype=BF16, device="cuda")
+    k_out = torch.empty(n, hkv, 128, dtype=BF16, device="cuda")
+    kc = torch.zeros(nblk, hkv, bs, 128, dtype=BF16, device="cuda")
+    vc = torch.zeros_like(kc)
+    ops.qknorm_rope_kvstore(dev(qkv), dev(pos), dev(qw), dev(kw), 1e-6, dev(table), dev(slots), q_out, k_out, kc, vc,
+                            h, hkv)
+    # norm is <=1 ulp vs the oracle; the rotation of a 1-ulp-different input can move the
+    # output by a couple of ulps, so compare with a small absolute tolerance as well
+    assert (q_out.cpu().float() - q_ref.float()).abs().max() <= 2 ** -5
+    assert (k_out.cpu().float() - k_ref.float()).abs().max() <= 2 ** -5
+    assert torch.equal(ref.from_head_major(vc.cpu()), vc_ref)
+    # the fused kernel must equal the unfused HIP kernels bit for bit
+    dq = dev(qkv)
+    qn = ops.rmsnorm(dq[:, : h * 128].view(n, h, 128), dev(qw), 1e-6)
+    kn = ops.rmsnorm(dq[:, h * 128: (h + hkv) * 128].view(n, hkv, 128), dev(kw), 1e-6)
+    q2 = ops.rope_neox(dev(pos), dev(table), qn)
+    k2 = ops.rope_neox(dev(pos), dev(table), kn)
+    assert torch.equal(q_out, q2) and torch.equal(k_out, k2)
+    kc2 = torch.zeros_like(kc)
+    vc2 = torch.zeros_like(vc)
+    ops.store_kvcache(k2, dq[:, (h + hkv) * 128:].view(n, hkv, 128), kc2, vc2, dev(slots))
+    assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
+
+
+# ------------------------------------------------------------------------------------------
+def _paged_setup(lens, hkv, bs, seed, extra_blocks=3):
+    """Random K/V for each sequence scattered into a paged cache (reference layout) with a
+    shuffled block table, -1 padded like engine/model_runner.py:125."""
+    gen = g(seed)
+    nb_each = [(n + bs - 1) // bs for n in lens]
+    total = sum(nb_each) + extra_blocks
+    perm = torch.randperm(total, generator=gen).tolist()
+    width = max(max(nb_each), 1)
+    bt = torch.full((len(lens), width), -1, dtype=torch.int32)
+    kc = torch.randn(total, bs, hkv, 128, generator=gen).to(BF16)  # garbage beyond the context
+    vc = torch.randn(total, bs, hkv, 128, generator=gen).to(BF16)
+    it = iter(perm)
+    for s, nb in enumerate(nb_each):
+        for j in range(nb):
+            bt[s, j] = next(it)
+    return kc, vc, bt
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1)])
+@pytest.mark.parametrize("lens", [[1], [255, 256, 257], [1, 100, 1023, 1024, 1025, 2048, 17], [4096, 3, 0, 700]])
+def test_paged_attn_decode(ops, hq, hkv, lens):
+    bs = 256
+    kc, vc, bt = _paged_setup(lens, hkv, bs, seed=20 + len(lens))
+    b = len(lens)
+    q = torch.randn(b, hq, 128, generator=g(21)).to(BF16)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    scale = 128 ** -0.5
+    o_ref = ref.flash_attn_with_kvcache(q.unsqueeze(1), kc, vc, ctx, bt, scale).squeeze(1)
+    max_ctx = 4096
+    btw = torch.full((b, max_ctx // bs), -1, dtype=torch.int32)
+    btw[:, : bt.shape[1]] = bt
+    ws = torch.empty(ops.paged_attn_decode_workspace_bytes(b, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    o = ops.paged_attn_decode(dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(btw), dev(ctx), scale,
+                              max_ctx, ws)
+    err = (o.cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+    for i, n in enumerate(lens):
+        if n == 0:
+            assert torch.count_nonzero(o[i]) == 0  # padded rows produce zeros
+
+
+def test_paged_attn_decode_large_batch(ops):
+    """bench-like shape: batch 256, contexts 100..2048, group size 2 (Qwen3-0.6B)."""
+    gen = g(30)
+    lens = torch.randint(100, 2049, (256,), generator=gen).tolist()
+    hq, hkv, bs = 16, 8, 256
+    kc, vc, bt = _paged_setup(lens, hkv, bs, seed=31)
+    q = torch.randn(256, hq, 128, generator=gen).to(BF16)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    scale = 128 ** -0.5
+    o_ref = ref.flash_attn_with_kvcache(q.unsqueeze(1), kc, vc, ctx, bt, scale).squeeze(1)
+    max_ctx = 4096
+    btw = torch.full((256, max_ctx // bs), -1, dtype=torch.int32)
+    btw[:, : bt.shape[1]] = bt
+    ws = torch.empty(ops.paged_attn_decode_workspace_bytes(256, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    o = ops.paged_attn_decode(dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(btw), dev(ctx), scale,
+                              max_ctx, ws)
+    err = (o.cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+
+
+# ------------------------------------------------------------------------------------------
+def _cu(lens):
+    return torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (8, 1)])
+@pytest.mark.parametrize("lens", [[1], [128], [129, 64, 300], [5, 1000, 33, 257]])
+def test_prefill_contiguous(ops, hq, hkv, lens):
+    n = sum(lens)
+    gen = g(40)
+    q = torch.randn(n, hq, 128, generator=gen).to(BF16)
+    qkv = torch.randn(n, 3 * hkv * 128, generator=gen).to(BF16)
+    k = qkv[:, hkv * 128: 2 * hkv * 128].view(n, hkv, 128)     # token-strided views
+    v = qkv[:, 2 * hkv * 128:].view(n, hkv, 128)
+    cu = _cu(lens)
+    scale = 128 ** -0.5
+    o_ref = ref.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, scale, True, None)
+    dqkv = dev(qkv)
+    o = ops.attn_prefill_varlen(dev(q), dqkv[:, hkv * 128: 2 * hkv * 128].view(n, hkv, 128),
+                                dqkv[:, 2 * hkv * 128:].view(n, hkv, 128), dev(cu), dev(cu), max(lens), scale)
+    err = (o.cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1)])
+@pytest.mark.parametrize("lq_lk", [[(1, 257)], [(100, 356), (256, 256), (7, 1031)], [(300, 812), (64, 64)]])
+def test_prefill_paged_prefix(ops, hq, hkv, lq_lk):
+    """Prefix-cache / chunked-prefill path: Lq < Lk, K/V from the paged cache, mask bottom-right."""
+    bs = 256
+    lqs = [a for a, _ in lq_lk]
+    lks = [b for _, b in lq_lk]
+    kc, vc, bt = _paged_setup(lks, hkv, bs, seed=50)
+    gen = g(51)
+    q = torch.randn(sum(lqs), hq, 128, generator=gen).to(BF16)
+    cuq, cuk = _cu(lqs), _cu(lks)
+    scale = 128 ** -0.5
+    o_ref = ref.flash_attn_varlen_func(q, kc, vc, max(lqs), cuq, max(lks), cuk, scale, True, bt)
+    o = ops.attn_prefill_varlen(dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(cuq), dev(cuk),
+                                max(lqs), scale, block_tables=dev(bt))
+    err = (o.cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+
+
+def test_prefill_softmax_rescale_branch(ops):
+    """Force a large running-max jump at a late tile (guide §5.4 rule 26): spike one key."""
+    hq = hkv = 8
+    lens = [512]
+    gen = g(60)
+    q = torch.randn(512, hq, 128, generator=gen).to(BF16)
+    k = torch.randn(512, hkv, 128, generator=gen).to(BF16)
+    v = torch.randn(512, hkv, 128, generator=gen).to(BF16)
+    k[300] = (q[400] * 4).to(BF16)  # key 300 dominates query 400 (and is visible to it)
+    cu = _cu(lens)
+    scale = 128 ** -0.5
+    o_ref = ref.flash_attn_varlen_func(q, k, v, 512, cu, 512, cu, scale, True, None)
+    o = ops.attn_prefill_varlen(dev(q), dev(k), dev(v), dev(cu), dev(cu), 512, scale)
+    err = (o.cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+
+
+# ------------------------------------------------------------------------------------------
+def test_sampler_greedy_exact(ops):
+    b, vocab = 37, 151936
+    logits = torch.randn(b, vocab, generator=g(70)).to(BF16)
+    logits[3, 100] = logits[3, 90000] = 50.0  # tie -> lowest index
+    t = torch.zeros(b)
+    ws = torch.empty(ops.sample_workspace_bytes(b), dtype=torch.uint8, device="cuda")
+    out = ops.sample(dev(logits), dev(t), seed=1, offset=0, workspace=ws)
+    assert torch.equal(out.cpu(), ref.greedy(logits))
+    assert out[3].item() == 100
+
+
+def test_sampler_replay_with_host_rng(ops):
+    """T>0: the GPU pick must be the argmax of l/T - log E under the SAME Philox draw."""
+    b, vocab = 5, 4099  # ragged vocab exercises the tail path
+    logits = (torch.randn(b, vocab, generator=g(71)) * 2).to(BF16)
+    t = torch.tensor([0.6, 1.0, 0.3, 2.0, 0.6])
+    ws = torch.empty(ops.sample_workspace_bytes(b), dtype=torch.uint8, device="cuda")
+    out = ops.sample(dev(logits), dev(t), seed=1234, offset=77, workspace=ws).cpu()
+    for r in range(b):
+        e = torch.from_numpy(ops.sample_exponentials_host(1234, 77, r, 0, vocab))
+        keys = ref.sampler_keys(logits[r: r + 1], t[r: r + 1], e.unsqueeze(0))[0]
+        assert keys[out[r]] >= keys.max() - 1e-3
+
+
+def test_sampler_distribution(ops):
+    """chi-square goodness of fit of 20000 draws against softmax(l/T) on a small vocab."""
+    vocab, draws = 64, 20000
+    base = (torch.randn(vocab, generator=g(72)) * 1.5).to(BF16)
+    logits = base.unsqueeze(0).repeat(draws, 1).contiguous()
+    t = torch.full((draws,), 0.8)
+    ws = torch.empty(ops.sample_workspace_bytes(draws), dtype=torch.uint8, device="cuda")
+    out = ops.sample(dev(logits), dev(t), seed=99, offset=5, workspace=ws).cpu()
+    p = torch.softmax(base.float() / 0.8, dim=-1)
+    counts = torch.bincount(out, minlength=vocab).float()
+    expected = p * draws
+    keep = expected >= 5
+    chi2 = (((counts - expected) ** 2) / expected)[keep].sum().item()
+    dof = int(keep.sum()) - 1
+    assert chi2 < dof + 5 * math.sqrt(2 * dof), (chi2, dof)
+
+
+def test_errors_are_reported_not_thrown(ops):
+    x = torch.zeros(4, 1000 + 4, dtype=BF16, device="cuda")  # hidden not a multiple of 8
+    w = torch.zeros(1004, dtype=BF16, device="cuda")
+    with pytest.raises(ops.NvlError, match="multiple of 8"):
+        ops.rmsnorm(x, w, 1e-6)
