@@ -29,9 +29,13 @@ constexpr int kMinChunk = 128;
 __device__ __forceinline__ float dot8(const u32x4_t& a, const u32x4_t& b) {
   float acc = 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a[i]), __builtin_bit_cast(bf16x2_t, b[i]),
-                                          acc, false);
+  for (int i = 0; i < 4; ++i) {
+    // NB: bit_cast the scalar copies, not the vector-element expressions a[i]/b[i]: hipcc
+    // (ROCm 7.2) folds `__builtin_bit_cast(T, vec[i])` to element 0 for every i.
+    const unsigned int ai = a[i], bi = b[i];
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, ai), __builtin_bit_cast(bf16x2_t, bi), acc,
+                                          false);
+  }
   return acc;
 }
 
@@ -128,6 +132,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(
       for (int i = 0; i < kLoads; ++i) kd[i] = *reinterpret_cast<const u32x4_t*>(kp + i * 4 * 128);
 #pragma unroll
       for (int i = 0; i < kLoads; ++i) vd[i] = *reinterpret_cast<const u32x4_t*>(vp + i * 4 * 128);
+      // keep all 16 loads (16 KiB per wave) in flight before the first use: without this fence
+      // hipcc sinks the K loads between the dot products and serialises their latencies
+      __builtin_amdgcn_sched_barrier(0);
 
       float s[G][kLoads];
 #pragma unroll
@@ -257,13 +264,19 @@ int launch_decode(const void* q, const void* kc, const void* vc, const int32_t* 
                   const int32_t* ctx, void* out, int64_t batch, int hkv, int block_size, int64_t max_context,
                   float scale, float* part_o, float* part_ml, int max_chunks, int chunk, hipStream_t s) {
   const int hq = hkv * G;
-  static int cus = 0;
-  if (cus == 0) cus = nvl_device_cu_count();
-  int64_t grid = (int64_t)cus * 4;
+  const size_t lds = (size_t)kWaves * G * 130 * sizeof(float) + kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
+  // persistent grid = CUs x resident workgroups per CU (register-limited; queried once per G)
+  static int cus = 0, per_cu = 0;
+  if (cus == 0) {
+    cus = nvl_device_cu_count();
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, decode_attn_kernel<G>, 256, lds) != hipSuccess || n < 1) n = 2;
+    per_cu = n > 4 ? 4 : n;
+  }
+  int64_t grid = (int64_t)cus * per_cu;
   const int64_t max_items = batch * hkv * ((max_context + chunk - 1) / chunk);
   if (grid > max_items) grid = max_items;
   if (grid < 1) grid = 1;
-  const size_t lds = (size_t)kWaves * G * 130 * sizeof(float) + kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
   hipLaunchKernelGGL(decode_attn_kernel<G>, dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
                      (const bf16_t*)kc, (const bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, (int)batch, hkv,
                      block_size, chunk, max_chunks, scale * 1.4426950408889634f);
