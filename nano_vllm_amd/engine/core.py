@@ -1,0 +1,104 @@
+"""The engine loop behind `LLM`: tokenizer + scheduler on rank 0, one ModelRunner per GPU.
+
+Public surface identical to the reference's `LLMEngine` (nano-vllm engine/llm_engine.py:15-90):
+`LLMEngine(model, **kwargs)` (unknown kwargs ignored, :18-19), `add_request`, `step` ->
+(finished outputs, +prefill tokens | -decode batch), `is_finished`, `generate` (results in
+submission order, dicts with "text" and "token_ids"), `exit`.
+"""
+from __future__ import annotations
+
+import atexit
+from dataclasses import fields
+from time import perf_counter
+
+from ..api import Config, SamplingParams
+from .sched import Scheduler
+from .seq import Sequence
+
+
+def _worker_main(config, rank, event):
+    from .runner import ModelRunner
+    ModelRunner(config, rank, event)       # never returns until "exit" (runner.loop)
+
+
+class LLMEngine:
+
+    def __init__(self, model, **kwargs):
+        known = {f.name for f in fields(Config)}
+        config = Config(model, **{k: v for k, v in kwargs.items() if k in known})
+        self.config = config
+        Sequence.block_size = config.kvcache_block_size
+        self.ps, self.events = [], []
+        if config.tensor_parallel_size > 1:
+            import torch.multiprocessing as mp
+            ctx = mp.get_context("spawn")
+            for rank in range(1, config.tensor_parallel_size):
+                event = ctx.Event()
+                proc = ctx.Process(target=_worker_main, args=(config, rank, event))
+                proc.start()
+                self.ps.append(proc)
+                self.events.append(event)
+        from .runner import ModelRunner
+        self.model_runner = ModelRunner(config, 0, self.events)     # also fills config.num_kvcache_blocks
+        from transformers import AutoTokenizer
+        self.tokenizer = AutoTokenizer.from_pretrained(config.model, use_fast=True)
+        config.eos = self.tokenizer.eos_token_id if self.tokenizer.eos_token_id is not None else -1
+        self.scheduler = Scheduler(config)
+        self._exited = False
+        atexit.register(self.exit)
+
+    def exit(self):
+        if self._exited:
+            return
+        self._exited = True
+        self.model_runner.call("exit")
+        del self.model_runner
+        for p in self.ps:
+            p.join()
+
+    def add_request(self, prompt: str | list[int], sampling_params: SamplingParams):
+        if isinstance(prompt, str):
+            prompt = self.tokenizer.encode(prompt)
+        assert len(prompt) > 0, "empty prompt"
+        self.scheduler.add(Sequence(prompt, sampling_params))
+
+    def step(self):
+        seqs, is_prefill = self.scheduler.schedule()
+        num_tokens = sum(s.num_scheduled_tokens for s in seqs) if is_prefill else -len(seqs)
+        token_ids = self.model_runner.call("run", seqs, is_prefill)
+        self.scheduler.postprocess(seqs, token_ids, is_prefill)
+        outputs = [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
+        return outputs, num_tokens
+
+    def is_finished(self):
+        return self.scheduler.is_finished()
+
+    def generate(self, prompts, sampling_params, use_tqdm: bool = True):
+        from tqdm.auto import tqdm
+        pbar = tqdm(total=len(prompts), desc="Generating", dynamic_ncols=True, disable=not use_tqdm)
+        if not isinstance(sampling_params, list):
+            sampling_params = [sampling_params] * len(prompts)
+        for prompt, sp in zip(prompts, sampling_params):
+            self.add_request(prompt, sp)
+        done: dict[int, list[int]] = {}
+        prefill_tps = decode_tps = 0.0
+        while not self.is_finished():
+            t0 = perf_counter()
+            finished, num_tokens = self.step()
+            dt = perf_counter() - t0
+            if num_tokens > 0:
+                prefill_tps = num_tokens / dt
+            else:
+                decode_tps = -num_tokens / dt
+            if use_tqdm:
+                pbar.set_postfix({"Prefill": f"{int(prefill_tps)}tok/s", "Decode": f"{int(decode_tps)}tok/s"})
+            for seq_id, toks in finished:
+                done[seq_id] = toks
+                pbar.update(1)
+        pbar.close()
+        ordered = [done[k] for k in sorted(done)]
+        return [{"text": self.tokenizer.decode(toks), "token_ids": toks} for toks in ordered]
+
+
+class LLM(LLMEngine):
+    """The user-facing name (`from nanovllm import LLM`); behaviour is entirely LLMEngine's."""

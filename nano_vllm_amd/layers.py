@@ -1,0 +1,298 @@
+"""Op-level drop-in layers: same class names, constructor arguments and forward signatures as
+the reference's `nanovllm.layers.*`, implemented on the hand-written gfx950 kernels
+(`nano_vllm_amd.ops` -> libnvl_hip.so). GEMMs and the embedding gather stay on PyTorch-ROCm
+(hipBLASLt) — SURVEY.md §2c K9/K10.
+
+Reference interfaces mirrored (file:line in GeeeekExplorer/nano-vllm):
+  RMSNorm            layers/layernorm.py:5-50
+  RotaryEmbedding    layers/rotary_embedding.py:17-59 (+ get_rope)
+  SiluAndMul         layers/activation.py:6-11
+  Attention          layers/attention.py:43-75
+  Sampler            layers/sampler.py:5-12
+  *Linear            layers/linear.py:12-156
+  VocabParallelEmbedding / ParallelLMHead   layers/embed_head.py:9-66
+
+There is no eager-PyTorch fallback for the hot ops: tensors must live on the GPU.
+"""
+from __future__ import annotations
+
+from functools import lru_cache
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops, tp
+from .attn_meta import get_context
+
+
+# ------------------------------------------------------------------------------------------------
+class RMSNorm(nn.Module):
+    """y = bf16(x32 * rsqrt(mean x32^2 + eps) * w32); with `residual`: fused add, residual updated."""
+
+    def __init__(self, hidden_size: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(hidden_size), requires_grad=False)
+
+    def forward(self, x: torch.Tensor, residual: torch.Tensor | None = None):
+        if residual is None:
+            return ops.rmsnorm(x, self.weight, self.eps)
+        # the reference returns (normed, bf16(x + residual)); we update `residual` in place
+        y = ops.add_rmsnorm(x, residual, self.weight, self.eps)
+        return y, residual
+
+
+class SiluAndMul(nn.Module):
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        lead = x.shape[:-1]
+        y = ops.silu_mul(x.reshape(-1, x.shape[-1]))
+        return y.view(*lead, y.shape[-1])
+
+
+class RotaryEmbedding(nn.Module):
+
+    def __init__(self, head_size: int, rotary_dim: int, max_position_embeddings: int, base: float) -> None:
+        super().__init__()
+        assert rotary_dim == head_size == 128, "libnvl kernels are built for head_dim 128"
+        self.head_size = head_size
+        # fp32 table cos || sin, computed on the host exactly as rotary_embedding.py:29-34
+        inv_freq = 1.0 / (base ** (torch.arange(0, rotary_dim, 2, dtype=torch.float, device="cpu") / rotary_dim))
+        t = torch.arange(max_position_embeddings, dtype=torch.float, device="cpu")
+        freqs = torch.einsum("i,j -> ij", t, inv_freq)
+        table = torch.cat((freqs.cos(), freqs.sin()), dim=-1)
+        self.register_buffer("cos_sin_cache", table.contiguous(), persistent=False)   # [max_pos, 128]
+
+    def forward(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor):
+        table = self.cos_sin_cache
+        return ops.rope_neox(positions, table, query), ops.rope_neox(positions, table, key)
+
+
+@lru_cache(4)
+def _rope_singleton(head_size: int, rotary_dim: int, max_position: int, base: float, device: str):
+    return RotaryEmbedding(head_size, rotary_dim, max_position, base).to(device)
+
+
+def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, device=None) -> RotaryEmbedding:
+    """One shared table per geometry (the reference memoises with lru_cache(1), rotary_embedding.py:51-59)."""
+    if device is None:
+        device = f"cuda:{torch.cuda.current_device()}"
+    return _rope_singleton(head_size, rotary_dim, max_position, float(base), str(device))
+
+
+class Attention(nn.Module):
+    """Paged attention. `k_cache` / `v_cache` are injected by the runner; layout
+    [num_blocks, num_kv_heads, block_size, 128] (head-major — see include/nvl.h)."""
+
+    def __init__(self, num_heads: int, head_dim: int, scale: float, num_kv_heads: int):
+        super().__init__()
+        assert head_dim == 128, "libnvl kernels are built for head_dim 128"
+        self.num_heads, self.head_dim, self.scale, self.num_kv_heads = num_heads, head_dim, scale, num_kv_heads
+        self.k_cache = self.v_cache = torch.tensor([])
+
+    # -- reference-shaped entry point: q/k/v already normed + rotated ---------------------------
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        ctx = get_context()
+        has_cache = self.k_cache.numel() > 0 and self.v_cache.numel() > 0
+        if has_cache:
+            ops.store_kvcache(k, v, self.k_cache, self.v_cache, ctx.slot_mapping)
+        return self._attend(q, k, v, ctx)
+
+    # -- fused entry point: raw qkv GEMM output -> (q/k norm, rope, KV store) in one launch -------
+    def forward_fused(self, qkv: torch.Tensor, positions: torch.Tensor, q_norm_w, k_norm_w, eps: float,
+                      rope_table: torch.Tensor) -> torch.Tensor:
+        ctx = get_context()
+        n = qkv.shape[0]
+        hq, hkv = self.num_heads, self.num_kv_heads
+        has_cache = self.k_cache.numel() > 0
+        q = torch.empty((n, hq, 128), dtype=qkv.dtype, device=qkv.device)
+        need_k = ctx.is_prefill and ctx.block_tables is None      # non-paged prefill reads packed K
+        k = torch.empty((n, hkv, 128), dtype=qkv.dtype, device=qkv.device) if need_k else None
+        ops.qknorm_rope_kvstore(qkv, positions, q_norm_w, k_norm_w, eps, rope_table,
+                                ctx.slot_mapping if has_cache else None, q, k,
+                                self.k_cache if has_cache else None, self.v_cache if has_cache else None, hq, hkv)
+        v = qkv[:, (hq + hkv) * 128:].view(n, hkv, 128) if need_k else None
+        return self._attend(q, k, v, ctx)
+
+    def _attend(self, q, k, v, ctx) -> torch.Tensor:
+        if ctx.is_prefill:
+            if ctx.block_tables is not None:        # prefix cache / chunk continuation: read the cache
+                return ops.attn_prefill_varlen(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q, ctx.cu_seqlens_k,
+                                               ctx.max_seqlen_q, self.scale, block_tables=ctx.block_tables)
+            return ops.attn_prefill_varlen(q, k, v, ctx.cu_seqlens_q, ctx.cu_seqlens_k, ctx.max_seqlen_q, self.scale)
+        ws = ctx.decode_workspace
+        max_context = ctx.max_context or ctx.block_tables.shape[1] * self.k_cache.shape[2]
+        if ws is None:
+            ws = torch.empty(ops.paged_attn_decode_workspace_bytes(q.shape[0], self.num_heads, max_context),
+                             dtype=torch.uint8, device=q.device)
+        return ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens, self.scale,
+                                     max_context, ws)
+
+
+class Sampler(nn.Module):
+    """Exponential-race categorical sampling in one pass; temperature 0 => argmax (extension)."""
+
+    def __init__(self, seed: int = 0):
+        super().__init__()
+        self.seed = seed
+        self.calls = 0
+        self._ws = None
+
+    def forward(self, logits: torch.Tensor, temperatures: torch.Tensor, out: torch.Tensor | None = None,
+                offset_dev: torch.Tensor | None = None) -> torch.Tensor:
+        b = logits.shape[0]
+        need = ops.sample_workspace_bytes(max(b, 512))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != logits.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=logits.device)
+        if logits.dtype != torch.bfloat16:
+            logits = logits.to(torch.bfloat16)
+        offset = 0 if offset_dev is not None else self.calls
+        self.calls += 1
+        return ops.sample(logits, temperatures, self.seed, offset, self._ws, out=out, offset_dev=offset_dev)
+
+
+# ------------------------------------------------------------------------------------------------
+# TP-sharded linears. Shard layout follows layers/linear.py:54-156.
+def _divide(a: int, b: int) -> int:
+    assert a % b == 0, f"{a} is not divisible by {b}"
+    return a // b
+
+
+class LinearBase(nn.Module):
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False, tp_dim: int | None = None):
+        super().__init__()
+        self.tp_dim = tp_dim
+        self.tp_rank, self.tp_size = tp.world()
+        self.weight = nn.Parameter(torch.empty(output_size, input_size), requires_grad=False)
+        self.weight.weight_loader = self.weight_loader
+        if bias:
+            self.bias = nn.Parameter(torch.empty(output_size), requires_grad=False)
+            self.bias.weight_loader = self.weight_loader
+        else:
+            self.register_parameter("bias", None)
+
+    def _my_slice(self, loaded: torch.Tensor, dim: int) -> torch.Tensor:
+        size = loaded.shape[dim] // self.tp_size
+        return loaded.narrow(dim, self.tp_rank * size, size)
+
+    def weight_loader(self, param: nn.Parameter, loaded: torch.Tensor, shard_id=None):
+        raise NotImplementedError
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return F.linear(x, self.weight, self.bias)
+
+
+class ReplicatedLinear(LinearBase):
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False):
+        super().__init__(input_size, output_size, bias)
+
+    def weight_loader(self, param, loaded, shard_id=None):
+        param.data.copy_(loaded)
+
+
+class ColumnParallelLinear(LinearBase):
+    """Output features split across ranks: rank r holds rows [r*out/tp, (r+1)*out/tp)."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False):
+        _, size = tp.world()
+        super().__init__(input_size, _divide(output_size, size), bias, tp_dim=0)
+
+    def weight_loader(self, param, loaded, shard_id=None):
+        param.data.copy_(self._my_slice(loaded, 0))
+
+
+class MergedColumnParallelLinear(ColumnParallelLinear):
+    """Several column-parallel projections fused along the output dim (gate || up)."""
+
+    def __init__(self, input_size: int, output_sizes: list[int], bias: bool = False):
+        self.output_sizes = list(output_sizes)
+        super().__init__(input_size, sum(output_sizes), bias)
+
+    def weight_loader(self, param, loaded, shard_id=None):
+        off = sum(self.output_sizes[:shard_id]) // self.tp_size
+        size = self.output_sizes[shard_id] // self.tp_size
+        param.data.narrow(0, off, size).copy_(self._my_slice(loaded, 0))
+
+
+class QKVParallelLinear(ColumnParallelLinear):
+    """Per-rank rows = [q: H/tp*D | k: Hkv/tp*D | v: Hkv/tp*D]."""
+
+    def __init__(self, hidden_size: int, head_size: int, total_num_heads: int,
+                 total_num_kv_heads: int | None = None, bias: bool = False):
+        _, size = tp.world()
+        total_num_kv_heads = total_num_kv_heads or total_num_heads
+        self.head_size = head_size
+        self.num_heads = _divide(total_num_heads, size)
+        self.num_kv_heads = _divide(total_num_kv_heads, size)
+        super().__init__(hidden_size, (total_num_heads + 2 * total_num_kv_heads) * head_size, bias)
+
+    def weight_loader(self, param, loaded, shard_id=None):
+        q_rows = self.num_heads * self.head_size
+        kv_rows = self.num_kv_heads * self.head_size
+        off, size = {"q": (0, q_rows), "k": (q_rows, kv_rows), "v": (q_rows + kv_rows, kv_rows)}[shard_id]
+        param.data.narrow(0, off, size).copy_(self._my_slice(loaded, 0))
+
+
+class RowParallelLinear(LinearBase):
+    """Input features split across ranks; partial products are summed with an all-reduce
+    (RCCL over xGMI; chunk-overlapped on a side stream for prefill-sized inputs — tp.py)."""
+
+    def __init__(self, input_size: int, output_size: int, bias: bool = False):
+        _, size = tp.world()
+        super().__init__(_divide(input_size, size), output_size, bias, tp_dim=1)
+
+    def weight_loader(self, param, loaded, shard_id=None):
+        if param.data.ndim == 1:          # bias: replicated, added on rank 0 only
+            param.data.copy_(loaded)
+        else:
+            param.data.copy_(self._my_slice(loaded, 1))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return tp.linear_allreduce(x, self.weight, self.bias if self.tp_rank == 0 else None)
+
+
+class VocabParallelEmbedding(nn.Module):
+
+    def __init__(self, num_embeddings: int, embedding_dim: int):
+        super().__init__()
+        self.tp_rank, self.tp_size = tp.world()
+        self.num_embeddings = num_embeddings
+        self.num_embeddings_per_partition = _divide(num_embeddings, self.tp_size)
+        self.vocab_start_idx = self.num_embeddings_per_partition * self.tp_rank
+        self.vocab_end_idx = self.vocab_start_idx + self.num_embeddings_per_partition
+        self.weight = nn.Parameter(torch.empty(self.num_embeddings_per_partition, embedding_dim), requires_grad=False)
+        self.weight.weight_loader = self.weight_loader
+
+    def weight_loader(self, param, loaded, shard_id=None):
+        n = param.data.shape[0]
+        param.data.copy_(loaded.narrow(0, self.tp_rank * n, n))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.tp_size == 1:
+            return F.embedding(x, self.weight)
+        mine = (x >= self.vocab_start_idx) & (x < self.vocab_end_idx)
+        y = F.embedding((x - self.vocab_start_idx) * mine, self.weight)
+        y = y * mine.unsqueeze(1)
+        return tp.all_reduce(y)
+
+
+class ParallelLMHead(VocabParallelEmbedding):
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, bias: bool = False):
+        assert not bias
+        super().__init__(num_embeddings, embedding_dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor | None:
+        ctx = get_context()
+        if ctx.is_prefill:                                   # only each sequence's last token is sampled
+            x = x[(ctx.cu_seqlens_q[1:] - 1).long()].contiguous()
+        logits = F.linear(x, self.weight)
+        if self.tp_size == 1:
+            return logits
+        import torch.distributed as dist
+        parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
+        dist.gather(logits, parts, 0)
+        return torch.cat(parts, -1) if self.tp_rank == 0 else None

@@ -1,0 +1,189 @@
+"""Host logic (scheduler, block manager, sequence) — product vs oracle vs the REAL reference.
+
+* `test_matches_golden[...]`  : product scheduler and the oracle restatement reproduce, step for
+  step, traces recorded from the imported reference (tests/golden/sched_*.json, written by
+  oracle/make_golden.py). Runs anywhere (no GPU, no /root/reference).
+* `test_matches_live_reference[...]` : the same comparison against the reference imported live
+  (build container only).
+* known-answer tests for the xxh64 hash chain and unit tests of the edge rules of
+  Appendix A.2.
+"""
+import gzip
+import json
+import os
+
+import pytest
+
+from oracle import host_trace
+from oracle.engine import OracleEngine, chain_hash
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _ours():
+    from nano_vllm_amd.api import SamplingParams
+    from nano_vllm_amd.engine.sched import Scheduler
+    from nano_vllm_amd.engine.seq import Sequence
+    Sequence.block_size = 256
+    return (lambda cfg: Scheduler(cfg),
+            lambda p, mt, ie: Sequence(p, SamplingParams(temperature=1.0, max_tokens=mt, ignore_eos=ie)))
+
+
+class _OSeq:
+    """Attribute view over an OracleEngine sequence record."""
+
+    def __init__(self, rec):
+        self.rec = rec
+
+    num_scheduled_tokens = property(lambda s: s.rec["sched"])
+    num_cached_tokens = property(lambda s: s.rec["cached"])
+    block_table = property(lambda s: s.rec["table"])
+    token_ids = property(lambda s: s.rec["toks"])
+    num_prompt_tokens = property(lambda s: s.rec["n_prompt"])
+
+    def __len__(self):
+        return len(self.rec["toks"])
+
+
+class _OSched:
+    def __init__(self, cfg):
+        self.e = OracleEngine(None, cfg.num_kvcache_blocks, cfg.kvcache_block_size, cfg.max_num_seqs,
+                              cfg.max_num_batched_tokens, cfg.eos)
+        self.views = {}
+
+    def add(self, view):
+        pass  # the record was queued by make_sequence
+
+    def make_sequence(self, p, mt, ie):
+        rec = self.e.add(p, 1.0, mt, ie)
+        v = _OSeq(rec)
+        self.views[rec["id"]] = v
+        return v
+
+    def is_finished(self):
+        return not self.e.waiting and not self.e.running
+
+    def schedule(self):
+        batch, pre = self.e.schedule()
+        return [self.views[r["id"]] for r in batch], pre
+
+    def postprocess(self, batch, tokens, is_prefill):
+        self.e.postprocess([v.rec for v in batch], tokens, is_prefill)
+
+
+def _oracle_trace(name):
+    holder = {}
+
+    def mk_sched(cfg):
+        holder["s"] = _OSched(cfg)
+        return holder["s"]
+
+    return host_trace.run_trace(name, mk_sched, lambda p, mt, ie: holder["s"].make_sequence(p, mt, ie))
+
+
+def _load_golden(name):
+    with gzip.open(os.path.join(GOLDEN, f"sched_{name}.json.gz"), "rt") as fh:
+        return json.load(fh)
+
+
+def _assert_same(a, b, what):
+    assert len(a) == len(b), f"{what}: {len(a)} steps vs {len(b)}"
+    for i, (x, y) in enumerate(zip(a, b)):
+        assert x == y, f"{what}: first divergence at step {i}:\n{x}\nvs\n{y}"
+
+
+@pytest.mark.parametrize("name", sorted(host_trace.SCENARIOS))
+def test_matches_golden(name):
+    golden = _load_golden(name)
+    mk_sched, mk_seq = _ours()
+    _assert_same(host_trace.run_trace(name, mk_sched, mk_seq), golden, "product vs reference golden")
+    _assert_same(_oracle_trace(name), golden, "oracle vs reference golden")
+
+
+@pytest.mark.reference
+@pytest.mark.parametrize("name", sorted(host_trace.SCENARIOS))
+def test_matches_live_reference(name):
+    from oracle import ref_import
+    mods = ref_import.load_reference()
+    RefSched = mods["nanovllm.engine.scheduler"].Scheduler
+    RefSeq = mods["nanovllm.engine.sequence"].Sequence
+    RefSP = mods["nanovllm.sampling_params"].SamplingParams
+    RefSeq.block_size = 256
+    ref = host_trace.run_trace(name, lambda cfg: RefSched(cfg),
+                               lambda p, mt, ie: RefSeq(p, RefSP(temperature=1.0, max_tokens=mt, ignore_eos=ie)))
+    mk_sched, mk_seq = _ours()
+    _assert_same(host_trace.run_trace(name, mk_sched, mk_seq), ref, "product vs live reference")
+    _assert_same(_oracle_trace(name), ref, "oracle vs live reference")
+    _assert_same(_load_golden(name), ref, "committed golden vs live reference")
+
+
+def test_scenarios_exercise_the_hard_paths():
+    """The golden traces must actually contain prefix-cache hits, preemption and chunked prefill."""
+    g = _load_golden("prefix_cache")
+    assert any(any(c > 0 for c in st["cached"]) for st in g[:-1] if st["prefill"]), "no prefix-cache hit"
+    g = _load_golden("preempt")
+    seen, preempted = set(), False
+    for st in g[:-1]:
+        if st["prefill"]:
+            preempted |= any(s in seen and c == 0 for s, c in zip(st["seqs"], st["cached"]))
+        else:
+            seen.update(st["seqs"])
+    assert preempted, "no preemption (re-prefill of a sequence that had been decoding)"
+    g = _load_golden("chunked")
+    assert any(st["prefill"] and len(st["seqs"]) == 1 and st["cached"][0] > 0 and st["cached"][0] % 256 != 0
+               for st in g[:-1]), "no chunked-prefill continuation"
+
+
+def test_hash_known_answers():
+    """xxh64 chain over int64-LE token bytes with an 8-byte LE prefix (block_manager.py:35-41)."""
+    from nano_vllm_amd.engine.kv_blocks import BlockManager
+    for fn in (BlockManager.compute_hash, chain_hash):
+        assert fn([1, 2, 3]) == 9771088612715187706
+        assert fn([1, 2, 3], 5) == 6749565444396405819
+
+
+def test_block_manager_edge_rules():
+    from nano_vllm_amd.api import SamplingParams
+    from nano_vllm_amd.engine.kv_blocks import BlockManager
+    from nano_vllm_amd.engine.seq import Sequence
+    Sequence.block_size = 256
+    bm = BlockManager(8, 256)
+    a = Sequence(list(range(600)), SamplingParams())
+    assert bm.can_allocate(a) == 0
+    bm.allocate(a, 0)
+    assert a.block_table == [0, 1, 2] and bm.num_free == 5
+    a.num_scheduled_tokens = 600
+    bm.hash_blocks(a)                       # two full blocks get hashed, the partial third does not
+    assert bm.block_hash[0] != -1 and bm.block_hash[1] != -1 and bm.block_hash[2] == -1
+    b = Sequence(list(range(512)), SamplingParams())     # exactly 2 full blocks: last block never reused
+    assert bm.can_allocate(b) == 1
+    bm.allocate(b, 1)
+    assert b.block_table[0] == 0 and bm.ref_count[0] == 2 and b.num_cached_tokens == 256
+    bm.deallocate(a)
+    assert bm.ref_count[0] == 1 and bm.free_block_ids[-2:] == [2, 1]   # freed in reverse, prefix survives
+    c = Sequence(list(range(600)), SamplingParams())
+    assert bm.can_allocate(c) == 2          # block 1 is free but still hashed: revivable
+    bm.allocate(c, 2)
+    assert c.block_table[:2] == [0, 1] and bm.ref_count[1] == 1 and 1 not in bm.free_block_ids
+    # can_append / may_append only when the new token opens a block (len % 256 == 1)
+    d = Sequence(list(range(256)), SamplingParams())
+    bm.allocate(d, bm.can_allocate(d))
+    d.append_token(5)
+    n_before = len(d.block_table)
+    assert bm.can_append(d)
+    bm.may_append(d)
+    assert len(d.block_table) == n_before + 1
+
+
+def test_sequence_pickle_is_slim():
+    import pickle
+    from nano_vllm_amd.api import SamplingParams
+    from nano_vllm_amd.engine.seq import Sequence
+    s = Sequence(list(range(1000)), SamplingParams(max_tokens=5))
+    s.block_table = [3, 4, 5, 6]
+    big = len(pickle.dumps(s))
+    s.is_prefill = False
+    small = len(pickle.dumps(s))
+    assert small < 200 < big
+    t = pickle.loads(pickle.dumps(s))
+    assert t.last_token == 999 and t.block_table == [3, 4, 5, 6] and t.num_tokens == 1000 and t.seq_id == s.seq_id
