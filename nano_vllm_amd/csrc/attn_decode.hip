@@ -16,6 +16,7 @@
 // served from one K/V read. Split-KV partials (m, l, O) go to a workspace and are merged by a
 // second tiny kernel.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -254,6 +255,214 @@ __global__ __launch_bounds__(128) void decode_combine_kernel(const float* __rest
   out[row * 128 + d] = (bf16_t)r;
 }
 
+// ================================================================================================
+// Stream variant: every WAVE is an independent worker over an equal share of the flattened
+// (sequence, kv-head, 32-token tile) space — no workgroup barriers or LDS merge in the loop, and
+// load balance to within one 16 KiB tile regardless of how ragged the context lengths are.
+// A wave's share may cover the tail of one (b, h), several whole short ones and the head of
+// another; it emits one split partial per (b, h) segment into slot k = wave - first_wave(b, h).
+constexpr int kMinTilesPerWave = 4;
+
+template <bool NT>
+__device__ __forceinline__ u32x4_t load16(const bf16_t* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+  else return *reinterpret_cast<const u32x4_t*>(p);
+}
+
+template <int G, bool NT, int OCC>
+__global__ __launch_bounds__(256, OCC) void decode_stream_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+    const int32_t* __restrict__ block_tables, int64_t bt_stride, const int32_t* __restrict__ ctx,
+    float* __restrict__ part_o, float* __restrict__ part_ml, int* __restrict__ meta, int batch, int hkv,
+    int block_size, int slots, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* wsum = reinterpret_cast<int*>(smem_raw);
+  int* pre = wsum + kWaves;  // tile prefix [batch + 1]
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane & 15, rq = lane >> 4;
+  const int hq = hkv * G;
+
+  chunk_prefix(ctx, batch, kTile, pre, wsum);
+  __syncthreads();
+  const int64_t total = (int64_t)pre[batch] * hkv;
+  const int64_t nwaves = (int64_t)gridDim.x * kWaves;
+  int64_t per = (total + nwaves - 1) / nwaves;
+  if (per < kMinTilesPerWave) per = kMinTilesPerWave;
+  const int64_t wid = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t g1 = min(total, (wid + 1) * per);
+
+  for (int64_t g = wid * per; g < g1;) {
+    int lo = 0, hi = batch;  // largest b with hkv * pre[b] <= g
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)pre[mid] * hkv <= g) lo = mid; else hi = mid;
+    }
+    const int b = lo;
+    const int nb = pre[b + 1] - pre[b];                 // tiles per kv-head of this sequence (> 0 here)
+    const int64_t base_b = (int64_t)pre[b] * hkv;
+    const int r = (int)(g - base_b);
+    const int h = r / nb;
+    const int t0 = r - h * nb;
+    const int run = (int)min((int64_t)(nb - t0), g1 - g);
+    const int len = ctx[b];
+
+    u32x4_t qf[G];
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg)
+      qf[gg] = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)b * hq + h * G + gg) * 128 + sub * 8);
+    float m[G], l[G], o[G][8];
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+      m[gg] = kNegBig;
+      l[gg] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[gg][j] = 0.f;
+    }
+
+    for (int ti = t0; ti < t0 + run; ++ti) {
+      const int t = ti * kTile;
+      const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
+      const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
+      const bf16_t* kp = kc + base;
+      const bf16_t* vp = vc + base;
+      u32x4_t kd[kLoads], vd[kLoads];
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) kd[i] = load16<NT>(kp + i * 4 * 128);
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) vd[i] = load16<NT>(vp + i * 4 * 128);
+      __builtin_amdgcn_sched_barrier(0);  // all 16 loads in flight before the first use
+
+      float s[G][kLoads];
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) {
+        const bool valid = (t + i * 4 + rq) < len;
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) {
+          const float d = row16_allreduce_sum(dot8(kd[i], qf[gg]));
+          s[gg][i] = valid ? d * scale_log2e : kNegBig;
+        }
+      }
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) {
+        float mx = s[gg][0];
+#pragma unroll
+        for (int i = 1; i < kLoads; ++i) mx = fmaxf(mx, s[gg][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m[gg], mx);
+        const float alpha = exp2f(m[gg] - mn);
+        m[gg] = mn;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+          const float p = exp2f(s[gg][i] - mn);
+          psum += p;
+          s[gg][i] = round_bf16(p);
+        }
+        l[gg] = l[gg] * alpha + psum;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[gg][j] *= alpha;
+      }
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) {
+        float vf[8];
+        unpack8(vd[i], vf);
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[gg][j] = fmaf(s[gg][i], vf[j], o[gg][j]);
+      }
+    }
+
+    // fold the wave's 4 row-groups and emit the partial of this (b, h) segment
+    const int64_t seg0 = base_b + (int64_t)h * nb;                 // first global tile of (b, h)
+    const int first = (int)(seg0 / per);
+    const int k = (int)(wid - first);
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+      l[gg] += __shfl_xor(l[gg], 16, 64);
+      l[gg] += __shfl_xor(l[gg], 32, 64);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        o[gg][j] += __shfl_xor(o[gg][j], 16, 64);
+        o[gg][j] += __shfl_xor(o[gg][j], 32, 64);
+      }
+    }
+    if (rq == 0) {
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) {
+        const int64_t pidx = ((int64_t)b * hq + h * G + gg) * slots + k;
+        float* dst = part_o + pidx * 128 + sub * 8;
+        *reinterpret_cast<f32x4_t*>(dst) = f32x4_t{o[gg][0], o[gg][1], o[gg][2], o[gg][3]};
+        *reinterpret_cast<f32x4_t*>(dst + 4) = f32x4_t{o[gg][4], o[gg][5], o[gg][6], o[gg][7]};
+        if (sub == 0) {
+          part_ml[pidx * 2] = m[gg];
+          part_ml[pidx * 2 + 1] = l[gg];
+        }
+      }
+      if (sub == 0) meta[b * hkv + h] = (int)((seg0 + nb - 1) / per) - first + 1;   // #partials of (b, h)
+    }
+    g += run;
+  }
+}
+
+__global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float* __restrict__ part_o,
+                                                                     const float* __restrict__ part_ml,
+                                                                     const int* __restrict__ meta,
+                                                                     const int32_t* __restrict__ ctx,
+                                                                     bf16_t* __restrict__ out, int hq, int hkv,
+                                                                     int slots) {
+  const int b = blockIdx.x / hq;
+  const int head = blockIdx.x - b * hq;
+  const int64_t row = blockIdx.x;
+  const int cnt = ctx[b] > 0 ? meta[b * hkv + head / (hq / hkv)] : 0;
+  const int d = threadIdx.x;
+  const float* ml = part_ml + row * slots * 2;
+  const float* po = part_o + row * slots * 128;
+  float M = kNegBig;
+  for (int c = 0; c < cnt; ++c) M = fmaxf(M, ml[c * 2]);
+  float num = 0.f, den = 0.f;
+  for (int c = 0; c < cnt; ++c) {
+    const float f = exp2f(ml[c * 2] - M);
+    num += f * po[c * 128 + d];
+    den += f * ml[c * 2 + 1];
+  }
+  out[row * 128 + d] = (bf16_t)(cnt > 0 ? num / den : 0.f);
+}
+
+inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 2; }
+
+template <int G, bool NT, int OCC>
+int launch_decode_stream(const void* q, const void* kc, const void* vc, const int32_t* bt, int64_t bt_stride,
+                         const int32_t* ctx, void* out, int64_t batch, int hkv, int block_size, int64_t max_context,
+                         float scale, void* workspace, hipStream_t s) {
+  const int hq = hkv * G;
+  const int slots = stream_slots(max_context);
+  float* part_o = (float*)workspace;
+  float* part_ml = part_o + (size_t)batch * hq * slots * 128;
+  int* meta = (int*)(part_ml + (size_t)batch * hq * slots * 2);
+  const size_t lds = kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
+  static int cus = 0, per_cu = 0;
+  if (cus == 0) {
+    cus = nvl_device_cu_count();
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, decode_stream_kernel<G, NT, OCC>, 256, lds) != hipSuccess || n < 1) n = 2;
+    per_cu = n > 4 ? 4 : n;
+  }
+  int64_t grid = (int64_t)cus * per_cu;
+  const int64_t max_tiles = batch * hkv * ((max_context + kTile - 1) / kTile);
+  const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
+  if (grid > max_wg) grid = max_wg;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((decode_stream_kernel<G, NT, OCC>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
+                     (const bf16_t*)kc, (const bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (int)batch, hkv,
+                     block_size, slots, scale * 1.4426950408889634f);
+  hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
+                     meta, ctx, (bf16_t*)out, hq, hkv, slots);
+  return nvl_check_launch("nvl_paged_attn_decode");
+}
+
 inline int pick_chunk(int64_t batch, int hkv, int block_size) {
   (void)block_size;
   return (batch * hkv >= 1024) ? 256 : kMinChunk;
@@ -290,7 +499,18 @@ int launch_decode(const void* q, const void* kc, const void* vc, const int32_t* 
 extern "C" size_t nvl_paged_attn_decode_workspace_bytes(int64_t max_batch, int num_q_heads, int64_t max_context) {
   if (max_batch <= 0 || num_q_heads <= 0 || max_context <= 0) return 0;
   const int64_t max_chunks = (max_context + kMinChunk - 1) / kMinChunk;
-  return (size_t)max_batch * num_q_heads * max_chunks * 130 * sizeof(float);
+  const size_t a = (size_t)max_batch * num_q_heads * max_chunks * 130 * sizeof(float);
+  const size_t b = (size_t)max_batch * num_q_heads * (stream_slots(max_context) * 130 * sizeof(float) + sizeof(int));
+  return a > b ? a : b;
+}
+
+static int decode_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("NVL_DECODE_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
 }
 
 extern "C" int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
@@ -316,6 +536,30 @@ extern "C" int nvl_paged_attn_decode(const void* q, const void* k_cache, const v
   float* part_o = (float*)workspace;
   float* part_ml = part_o + (size_t)batch * num_q_heads * max_chunks * 128;
   hipStream_t s = (hipStream_t)stream;
+  const int variant = decode_variant();
+  if (variant >= 1) {
+    NVL_REQUIRE(workspace_bytes >= nvl_paged_attn_decode_workspace_bytes(batch, num_q_heads, max_context),
+                "nvl_paged_attn_decode: workspace too small for the stream variant");
+#define NVL_STREAM_ARGS q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch, num_kv_heads, block_size, max_context, softmax_scale, workspace, s
+#define NVL_STREAM_CASE(GG)                                                        \
+  case GG:                                                                         \
+    switch (variant) {                                                             \
+      case 2: return launch_decode_stream<GG, true, 1>(NVL_STREAM_ARGS);           \
+      case 3: return launch_decode_stream<GG, false, (GG <= 2 ? 4 : 1)>(NVL_STREAM_ARGS); \
+      case 4: return launch_decode_stream<GG, true, (GG <= 2 ? 4 : 1)>(NVL_STREAM_ARGS);  \
+      default: return launch_decode_stream<GG, false, 1>(NVL_STREAM_ARGS);         \
+    }
+    switch (G) {
+      NVL_STREAM_CASE(1)
+      NVL_STREAM_CASE(2)
+      NVL_STREAM_CASE(4)
+      NVL_STREAM_CASE(8)
+      default:
+        nvl_set_error("nvl_paged_attn_decode: unsupported group size Hq/Hkv=%d (supported 1,2,4,8)", G);
+        return NVL_EUNSUPPORTED;
+    }
+#undef NVL_STREAM_CASE
+  }
 #define NVL_DECODE_CASE(GG)                                                                                     \
   case GG:                                                                                                      \
     return launch_decode<GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,           \
