@@ -201,7 +201,7 @@ def roofline_replay(torch, runner, rec) -> dict:
     achieved = total_bytes / (total_ms * 1e-3) / 1e9
     step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * 2 * L
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None, "kernel": "decode_attn_kernel<2> (nvl_paged_attn_decode)",
+            "traffic": None, "kernel": "decode_stream_kernel<2> (nvl_paged_attn_decode)",
             "algorithmic_bytes_per_launch": total_bytes / launches, "avg_launch_us": total_ms * 1e3 / launches,
             "launches_timed": launches, "decode_steps_in_pass": rec["steps"],
             "kv_bytes_read_in_pass": step_bytes, "frac_of_measured_achievable_6.29TBps": achieved / 6290.0}

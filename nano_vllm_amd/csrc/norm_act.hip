@@ -43,7 +43,13 @@ __global__ __launch_bounds__(T) void rmsnorm_kernel(const bf16_t* __restrict__ x
   const int nchunks = hidden >> 3;
 
   float v[kMaxChunks][8];
+  u32x4_t wraw[kMaxChunks];   // weights fetched up front: keeps them off the post-reduction critical path
   float ss = 0.f;
+#pragma unroll
+  for (int c = 0; c < kMaxChunks; ++c) {
+    const int chunk = threadIdx.x + c * T;
+    if (chunk < nchunks) wraw[c] = *reinterpret_cast<const u32x4_t*>(weight + chunk * 8);
+  }
 #pragma unroll
   for (int c = 0; c < kMaxChunks; ++c) {
     const int chunk = threadIdx.x + c * T;
@@ -68,9 +74,8 @@ __global__ __launch_bounds__(T) void rmsnorm_kernel(const bf16_t* __restrict__ x
   for (int c = 0; c < kMaxChunks; ++c) {
     const int chunk = threadIdx.x + c * T;
     if (chunk < nchunks) {
-      u32x4_t ww = *reinterpret_cast<const u32x4_t*>(weight + chunk * 8);
       float wf[8], o[8];
-      unpack8(ww, wf);
+      unpack8(wraw[c], wf);
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = v[c][i] * rstd * wf[i];
       *reinterpret_cast<u32x4_t*>(yr + chunk * 8) = pack8(o);

@@ -1,5 +1,5 @@
-"""Decode-attention micro-benchmark + correctness check for the variant selected by
-NVL_DECODE_VARIANT. Prints one JSON line."""
+"""Decode-attention micro-benchmark + correctness check of the shipped kernel.
+Prints one JSON line."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,7 @@ from nano_vllm_amd import ops
 from oracle import ops as ref
 BF16 = torch.bfloat16
 ops.load_library()
-res = {"variant": os.environ.get("NVL_DECODE_VARIANT", "0")}
+res = {}
 
 def check(lens, hq, hkv):
     bs = 256
