@@ -111,6 +111,23 @@ def main():
 
     runner.prepare_decode = prepare_spy
 
+    # ---- host-side time of the timed pass (serial with the GPU: every step ends in a D2H sync) -----
+    host = {"schedule_s": 0.0, "postprocess_s": 0.0, "prepare_decode_s": 0.0}
+
+    def timed(fn, key):
+        def wrapper(*a, **kw):
+            t = time.perf_counter()
+            try:
+                return fn(*a, **kw)
+            finally:
+                if rec["on"]:
+                    host[key] += time.perf_counter() - t
+        return wrapper
+
+    llm.scheduler.schedule = timed(llm.scheduler.schedule, "schedule_s")
+    llm.scheduler.postprocess = timed(llm.scheduler.postprocess, "postprocess_s")
+    runner.prepare_decode = timed(runner.prepare_decode, "prepare_decode_s")
+
     llm.generate(["Benchmark: "], SamplingParams(), use_tqdm=False)          # reference bench.py:22
     for _ in range(args.warmup):
         llm.generate(prompts, sps, use_tqdm=False)
@@ -157,6 +174,7 @@ def main():
         result["config"]["baseline_note"] = "vs_baseline = value / 1434.13 tok/s (reference README, RTX 4070 Laptop: other hardware)"
 
     if rank == 0 and not args.no_roofline and rec["samples"]:
+        result["config"]["host_seconds_in_last_step"] = {k: round(v, 4) for k, v in host.items()}
         result["roofline"] = roofline_replay(torch, runner, rec)
     if rank == 0 and not args.no_cpu_baseline:
         try:
@@ -173,38 +191,35 @@ def main():
 
 def roofline_replay(torch, runner, rec) -> dict:
     """Time the decode-attention kernel alone on the recorded batches (HIP events on the launch
-    stream, every layer's cache => cold K/V like in the real step)."""
-    from nano_vllm_amd import ops
+    stream, every layer's cache => cold K/V like in the real step). Same code path as
+    tools/attn_replay.py, which is the command the rocprofv3 duration/PMC profiles are taken with."""
+    from tools.attn_replay import replay
     geo = runner.geo
     hq, hkv, L = geo["heads"], geo["kv_heads"], geo["layers"]
-    scale = 128 ** -0.5
-    max_ctx = runner.config.max_model_len
-    dev = runner.device
-    total_ms, total_bytes, launches = 0.0, 0, 0
-    q_all = torch.randn(runner.max_bs, hq, 128, device=dev, dtype=torch.bfloat16)
-    out = torch.empty_like(q_all)
-    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for n, ctx, bt in rec["samples"]:
-        ctx_d = torch.from_numpy(ctx).to(dev)
-        bt_d = torch.from_numpy(bt).to(dev)
-        q = q_all[:n]
-        for rep in range(2):                       # rep 0 warms nothing useful (caches are 100s of MB); keep rep 1
-            start.record()
-            for layer in range(L):
-                ops.paged_attn_decode(q, runner.kv_cache[0, layer], runner.kv_cache[1, layer], bt_d, ctx_d, scale,
-                                      max_ctx, runner.decode_ws, out=out[:n])
-            stop.record()
-            torch.cuda.synchronize()
-        total_ms += start.elapsed_time(stop)
-        total_bytes += int(ctx.sum()) * 2 * hkv * 128 * 2 * L
-        launches += L
-    achieved = total_bytes / (total_ms * 1e-3) / 1e9
+    r = replay(torch, runner.kv_cache, rec["samples"], hq, hkv, runner.config.max_model_len, runner.decode_ws)
+    achieved = r["achieved_GBps"]
     step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * 2 * L
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": None, "kernel": "decode_stream_kernel<2> (nvl_paged_attn_decode)",
-            "algorithmic_bytes_per_launch": total_bytes / launches, "avg_launch_us": total_ms * 1e3 / launches,
-            "launches_timed": launches, "decode_steps_in_pass": rec["steps"],
+            "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"]),
+            "kernel": f"decode_stream_kernel<{hq // hkv}> (nvl_paged_attn_decode)",
+            "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],
+            "launches_timed": r["launches_timed"], "decode_steps_in_pass": rec["steps"],
             "kv_bytes_read_in_pass": step_bytes, "frac_of_measured_achievable_6.29TBps": achieved / 6290.0}
+
+
+def pmc_traffic(alg_bytes_per_launch: float):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/pmc_traffic.json:
+    FETCH_SIZE summed over the decode_stream_kernel launches of tools/attn_replay.py, doubled as
+    MI355X_MICROARCH.md §HBM prescribes for 16 B/lane streaming reads on gfx950, divided by the
+    algorithmic bytes of the same launches). PMC counters cannot be read from inside this process,
+    so the ratio measured by that separate pass is applied to this run's bytes per launch; null
+    when no PMC pass has been recorded."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            ratio = float(json.load(fh)["hbm_read_bytes_over_algorithmic"])
+    except (OSError, KeyError, ValueError):
+        return None
+    return ratio * alg_bytes_per_launch
 
 
 def cpu_baseline(torch, llm, model_name, prompts, out_lens) -> dict:

@@ -1,0 +1,128 @@
+"""Replay the decode-attention launches of the bench workload WITHOUT the model.
+
+The host scheduler + block manager (pure Python) are driven through the reference bench.py
+workload (seed(0), 256 sequences, in/out U[100,1024]) with a fake token source, which yields the
+exact decode batches of the real run (context lengths and block tables depend only on the
+schedule, not on token values: ignore_eos). Every `--every`-th decode batch is then replayed
+through `nvl_paged_attn_decode` over all 28 layer caches (cold K/V, like in the real step) and
+timed with HIP events on the launch stream.
+
+This is the command the per-kernel profiles in profiles/ are taken with:
+
+  rocprofv3 --kernel-trace --stats ... -- python tools/attn_replay.py          (duration)
+  rocprofv3 --pmc FETCH_SIZE --kernel-include-regex decode_ ... -- python tools/attn_replay.py
+                                                                              (HBM traffic)
+
+Prints one JSON line; `algorithmic_bytes_per_launch` is sum_b len_b * 2 * Hkv * 128 * 2 B.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+from random import randint, seed
+from types import SimpleNamespace
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def bench_decode_batches(num_seqs: int = 256, num_blocks: int = 9380, every: int = 8, max_num_seqs: int = 512,
+                         max_num_batched_tokens: int = 16384, block_size: int = 256, max_model_len: int = 4096):
+    """Host-only pass of the bench workload. Returns (samples, stats): samples = list of
+    (n, ctx int32[n], block_table int32[n, max_blocks]) for every `every`-th decode step."""
+    from nano_vllm_amd.api import SamplingParams
+    from nano_vllm_amd.engine.sched import Scheduler
+    from nano_vllm_amd.engine.seq import Sequence
+    seed(0)
+    prompts = [[randint(0, 10000) for _ in range(randint(100, 1024))] for _ in range(num_seqs)]
+    outs = [randint(100, 1024) for _ in range(num_seqs)]
+    cfg = SimpleNamespace(max_num_seqs=max_num_seqs, max_num_batched_tokens=max_num_batched_tokens, eos=-1,
+                          kvcache_block_size=block_size, num_kvcache_blocks=num_blocks)
+    Sequence.block_size = block_size
+    sched = Scheduler(cfg)
+    for p, m in zip(prompts, outs):
+        sched.add(Sequence(p, SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=m)))
+    w = max_model_len // block_size
+    samples, steps, prefills, ctx_tokens, max_block = [], 0, 0, 0, 0
+    while not sched.is_finished():
+        batch, is_prefill = sched.schedule()
+        if is_prefill:
+            prefills += 1
+        else:
+            n = len(batch)
+            lens = np.fromiter((s.num_tokens for s in batch), dtype=np.int32, count=n)
+            ctx_tokens += int(lens.sum())
+            if steps % every == 0:
+                bt = np.full((n, w), -1, dtype=np.int32)
+                for i, s in enumerate(batch):
+                    bt[i, :len(s.block_table)] = s.block_table
+                    max_block = max(max_block, max(s.block_table))
+                samples.append((n, lens, bt))
+            steps += 1
+        sched.postprocess(batch, [1] * len(batch), is_prefill)
+    return samples, dict(decode_steps=steps, prefill_steps=prefills, ctx_tokens=ctx_tokens, max_block=max_block)
+
+
+def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: int = 2, pool_blocks: int | None = None):
+    """Time nvl_paged_attn_decode (main kernel + split combine) on the recorded batches.
+    kv_cache: [2, L, num_blocks, Hkv, block, 128]. Block ids are folded into the cache with a
+    modulo when the cache is smaller than the pool the schedule was recorded with."""
+    from nano_vllm_amd import ops
+    L, nblk = kv_cache.shape[1], kv_cache.shape[2]
+    dev = kv_cache.device
+    scale = 128 ** -0.5
+    max_bs = max(n for n, _, _ in samples)
+    q_all = torch.randn(max_bs, hq, 128, device=dev, dtype=torch.bfloat16)
+    out = torch.empty_like(q_all)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    total_ms, total_bytes, launches = 0.0, 0, 0
+    for n, ctx, bt in samples:
+        if bt.max() >= nblk:
+            bt = np.where(bt >= 0, bt % nblk, bt).astype(np.int32)
+        ctx_d = torch.from_numpy(np.ascontiguousarray(ctx)).to(dev)
+        bt_d = torch.from_numpy(np.ascontiguousarray(bt)).to(dev)
+        q = q_all[:n]
+        for _ in range(reps):                       # keep the last rep (caches are 100s of MB: nothing stays warm)
+            start.record()
+            for layer in range(L):
+                ops.paged_attn_decode(q, kv_cache[0, layer], kv_cache[1, layer], bt_d, ctx_d, scale, max_ctx, ws,
+                                      out=out[:n])
+            stop.record()
+            torch.cuda.synchronize()
+        total_ms += start.elapsed_time(stop)
+        total_bytes += int(ctx.sum()) * 2 * hkv * 128 * 2 * L
+        launches += L
+    return dict(achieved_GBps=total_bytes / (total_ms * 1e-3) / 1e9, algorithmic_bytes_per_launch=total_bytes / launches,
+                avg_launch_us=total_ms * 1e3 / launches, launches_timed=launches, reps=reps)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--every", type=int, default=8)
+    ap.add_argument("--layers", type=int, default=28)
+    ap.add_argument("--hq", type=int, default=16)
+    ap.add_argument("--hkv", type=int, default=8)
+    ap.add_argument("--reps", type=int, default=2)
+    ap.add_argument("--pool-blocks", type=int, default=9380, help="KV pool the schedule is recorded with")
+    args = ap.parse_args()
+    import torch
+    from nano_vllm_amd import ops
+    ops.load_library()
+    samples, stats = bench_decode_batches(num_blocks=args.pool_blocks, every=args.every)
+    nblk = stats["max_block"] + 1
+    dev = torch.device("cuda", 0)
+    kv = torch.empty(2, args.layers, nblk, args.hkv, 256, 128, dtype=torch.bfloat16, device=dev)
+    for layer in range(args.layers):               # random (not zero) data: zero-filled inputs clock higher
+        kv[:, layer].normal_()
+    ws = torch.empty(ops.paged_attn_decode_workspace_bytes(512, args.hq, 4096), dtype=torch.uint8, device=dev)
+    r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps)
+    r.update(stats, kernel=f"decode_stream_kernel<{args.hq // args.hkv}>", kv_blocks_used=nblk, samples=len(samples),
+             frac_of_8TBps=r["achieved_GBps"] / 8000.0)
+    print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()

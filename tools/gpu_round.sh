@@ -1,0 +1,32 @@
+#!/bin/bash
+# One gpurun call: GPU tests, bench line, rocprofv3 kernel stats + PMC traffic of the attention replay.
+# Usage (from repo root on the GPU box): bash tools/gpu_round.sh <tag> [tests] [bench] [prof] [pmc] [probe]
+set -u
+TAG=${1:-r01}; shift || true
+WHAT="${*:-tests bench prof pmc}"
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+for w in $WHAT; do
+case $w in
+tests)
+  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log;;
+bench)
+  timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 3000 $OUT/bench.json;;
+prof)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_replay -o replay -- python $REPO/tools/attn_replay.py > $OUT/replay_under_rocprof.json 2> $OUT/replay_prof.err; echo "prof rc=$?")
+  f=$(find /tmp/prof_replay -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/replay_kernel_stats.csv && head -5 $OUT/replay_kernel_stats.csv;;
+pmc)
+  (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'decode_' -f csv -d /tmp/pmc_replay -o replay -- python $REPO/tools/attn_replay.py --reps 1 > $OUT/replay_under_pmc.json 2> $OUT/replay_pmc.err; echo "pmc rc=$?")
+  python tools/pmc_summary.py /tmp/pmc_replay $OUT/pmc_fetch_summary.json | tail -30;;
+benchprof)
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_bench -o bench -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err; echo "benchprof rc=$?")
+  f=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv && head -12 $OUT/bench_kernel_stats.csv | cut -c1-200;;
+probe)
+  timeout 600 python tools/gpu_probe.py > $OUT/probe.log 2>&1; cp gpurun_out/probe.json $OUT/ 2>/dev/null; tail -3 $OUT/probe.log;;
+replay)
+  timeout 600 python tools/attn_replay.py > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
+*) echo "unknown step $w";;
+esac
+done
