@@ -13,7 +13,7 @@ agg = defaultdict(lambda: [0.0, 0])
 for f in files:
     with open(f, newline="") as fh:
         for row in csv.DictReader(fh):
-            name = row.get("Kernel_Name", "?").split("(")[0][-80:]
+            name = row.get("Kernel_Name", "?").replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][-80:]
             key = (name, row.get("Counter_Name", "?"))
             agg[key][0] += float(row.get("Counter_Value", 0) or 0)
             agg[key][1] += 1
