@@ -81,6 +81,35 @@ int nvl_add_rmsnorm(const void* x, void* residual, const void* weight, void* y,
 int nvl_silu_mul(const void* x, int64_t x_row_stride, void* y,
                  int64_t rows, int inter, void* stream);
 
+/* ---- Skinny (decode-step) linear layers ---------------------------------------
+ * Replace F.linear as called by LinearBase.forward and its subclasses
+ * (layers/linear.py:54-156) when the row count is decode-sized (one row per
+ * running sequence; the reference reaches cuBLAS through torch here), with the
+ * reference's elementwise glue folded into the epilogue:
+ *   mode 0  out[m, n]   = bf16( x[m, :] . W[n, :] )                        bf16 [m, n]
+ *   mode 1  out[m, j]   = bf16( silu(bf16(x.W[j])) * bf16(x.W[n/2 + j]) )  bf16 [m, n/2]
+ *           (= SiluAndMul over the merged gate|up projection, layers/activation.py:8-11)
+ *   mode 2  part[s][m, n] = partial sums over K-slice s, fp32 [splits, m, n]; the
+ *           consumer nvl_add_rmsnorm_splitk rounds bf16(sum_s part[s]) — the same
+ *           rounding point as the bf16 GEMM output it replaces.
+ * x: [m, k] bf16 contiguous; weight: [n, k] bf16 contiguous (torch Linear layout).
+ * nvl_linear_decode_splits returns the number of K-slices the kernel will emit
+ * for (m, n, k, mode) (1 for modes 0/1) or 0 when the shape is not covered — the
+ * caller then keeps the library GEMM. */
+int nvl_linear_decode_splits(int64_t m, int n, int k, int mode);
+int nvl_linear_decode(const void* x, const void* weight, void* out,
+                      int64_t m, int n, int k, int mode, void* stream);
+
+/* Fused split-K reduction + residual add + RMSNorm: replaces
+ * RMSNorm.add_rms_forward (layers/layernorm.py:28-40) when its input is the
+ * fp32 partials of nvl_linear_decode mode 2:
+ *   xs = bf16(sum_s partials[s][row]); s = float(xs) + float(residual);
+ *   residual <- bf16(s); y = bf16( s * rsqrt(mean(s^2)+eps) * float(w) ).
+ * partials: [splits, rows, hidden] fp32 contiguous. */
+int nvl_add_rmsnorm_splitk(const float* partials, int splits, void* residual,
+                           const void* weight, void* y,
+                           int64_t rows, int hidden, float eps, void* stream);
+
 /* ---- Rotary embedding -----------------------------------------------------
  * Replaces RotaryEmbedding.forward / apply_rotary_emb
  * (layers/rotary_embedding.py:6-14, 37-48): neox (half-split) rotation from a

@@ -39,7 +39,12 @@ class RMSNorm(nn.Module):
         if residual is None:
             return ops.rmsnorm(x, self.weight, self.eps)
         # the reference returns (normed, bf16(x + residual)); we update `residual` in place
-        y = ops.add_rmsnorm(x, residual, self.weight, self.eps)
+        if x.dtype == torch.float32 and x.dim() == 3:
+            # x = fp32 split-K partials [S, N, hidden] of a decode-step RowParallelLinear
+            # (`forward_decode`): the slab sum is this kernel's prologue
+            y = ops.add_rmsnorm_splitk(x, residual, self.weight, self.eps)
+        else:
+            y = ops.add_rmsnorm(x, residual, self.weight, self.eps)
         return y, residual
 
 
@@ -181,7 +186,20 @@ class LinearBase(nn.Module):
         raise NotImplementedError
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.bias is None and _decode_sized(x) and ops.linear_decode_splits(
+                x.shape[0], self.weight.shape[0], self.weight.shape[1], ops.LINEAR_BF16):
+            return ops.linear_decode(x, self.weight, ops.LINEAR_BF16)
         return F.linear(x, self.weight, self.bias)
+
+
+# Row counts up to this use the hand-written skinny GEMM (nvl_linear_decode); above it the library
+# GEMM wins (measured crossover on MI355X, tools/gemm_bench.py).
+DECODE_LINEAR_MAX_ROWS = 256
+
+
+def _decode_sized(x: torch.Tensor) -> bool:
+    return (x.dim() == 2 and x.shape[0] <= DECODE_LINEAR_MAX_ROWS and x.dtype == torch.bfloat16 and x.is_cuda
+            and x.is_contiguous())
 
 
 class ReplicatedLinear(LinearBase):
@@ -215,6 +233,15 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
         off = sum(self.output_sizes[:shard_id]) // self.tp_size
         size = self.output_sizes[shard_id] // self.tp_size
         param.data.narrow(0, off, size).copy_(self._my_slice(loaded, 0))
+
+    def forward_silu(self, x: torch.Tensor) -> torch.Tensor:
+        """SiluAndMul(self(x)) for a gate|up pair; on decode-sized inputs the activation is the GEMM's
+        epilogue (one launch, no [N, 2*inter] round trip)."""
+        n, k = self.weight.shape
+        if (self.bias is None and len(self.output_sizes) == 2 and self.output_sizes[0] == self.output_sizes[1]
+                and _decode_sized(x) and ops.linear_decode_splits(x.shape[0], n, k, ops.LINEAR_SILU)):
+            return ops.linear_decode(x, self.weight, ops.LINEAR_SILU)
+        return ops.silu_mul(self.forward(x))
 
 
 class QKVParallelLinear(ColumnParallelLinear):
@@ -251,7 +278,19 @@ class RowParallelLinear(LinearBase):
             param.data.copy_(self._my_slice(loaded, 1))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.tp_size == 1:
+            return LinearBase.forward(self, x)
         return tp.linear_allreduce(x, self.weight, self.bias if self.tp_rank == 0 else None)
+
+    def forward_decode(self, x: torch.Tensor) -> torch.Tensor:
+        """Like forward, but on decode-sized inputs (TP=1) may return the GEMM's fp32 split-K partials
+        [S, N, out] instead of the bf16 sum; the only consumer is RMSNorm.forward(x, residual), which
+        sums and rounds them in its prologue."""
+        n, k = self.weight.shape
+        if (self.tp_size == 1 and self.bias is None and _decode_sized(x)
+                and ops.linear_decode_splits(x.shape[0], n, k, ops.LINEAR_PARTIAL)):
+            return ops.linear_decode(x, self.weight, ops.LINEAR_PARTIAL)
+        return self.forward(x)
 
 
 class VocabParallelEmbedding(nn.Module):

@@ -26,6 +26,9 @@ SIGNATURES = {
     "nvl_device_cu_count": (c_int, []),
     "nvl_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_void_p]),
     "nvl_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
+    "nvl_linear_decode_splits": (c_int, [c_int64, c_int, c_int, c_int]),
+    "nvl_linear_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "nvl_add_rmsnorm_splitk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "nvl_silu_mul": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "nvl_rope_neox": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "nvl_store_kvcache": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
@@ -134,6 +137,57 @@ def silu_mul(x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
         out = torch.empty((x.shape[0], inter), dtype=x.dtype, device=x.device)
     _check(lib().nvl_silu_mul(x.data_ptr(), x.stride(0), out.data_ptr(), x.shape[0], inter, _stream()))
     return out
+
+
+# ---- skinny (decode) linears ------------------------------------------------------------------
+LINEAR_BF16, LINEAR_SILU, LINEAR_PARTIAL = 0, 1, 2
+_splits_cache: dict[tuple, int] = {}
+
+
+def linear_decode_splits(m: int, n: int, k: int, mode: int) -> int:
+    """K-slices nvl_linear_decode emits for this shape (1 for modes 0/1); 0 = shape not covered."""
+    key = (m, n, k, mode)
+    r = _splits_cache.get(key)
+    if r is None:
+        r = _splits_cache[key] = lib().nvl_linear_decode_splits(m, n, k, mode)
+    return r
+
+
+def linear_decode(x: torch.Tensor, weight: torch.Tensor, mode: int = LINEAR_BF16,
+                  out: torch.Tensor | None = None) -> torch.Tensor:
+    """x [M, K] bf16, weight [N, K] bf16 (torch Linear layout). mode 0: bf16 [M, N];
+    mode 1: bf16 [M, N/2] = silu(x.Wgate) * (x.Wup); mode 2: fp32 split-K partials [S, M, N]."""
+    _dev(x, "x")
+    assert x.dim() == 2 and x.is_contiguous() and weight.is_contiguous()
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+    m, k = x.shape
+    n = weight.shape[0]
+    assert weight.shape[1] == k
+    splits = linear_decode_splits(m, n, k, mode)
+    if splits == 0:
+        raise NvlError(f"nvl_linear_decode does not cover m={m} n={n} k={k} mode={mode}")
+    if out is None:
+        if mode == LINEAR_PARTIAL:
+            out = torch.empty((splits, m, n), dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty((m, n // 2 if mode == LINEAR_SILU else n), dtype=torch.bfloat16, device=x.device)
+    _check(lib().nvl_linear_decode(x.data_ptr(), weight.data_ptr(), out.data_ptr(), m, n, k, mode, _stream()))
+    return out
+
+
+def add_rmsnorm_splitk(partials: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                       out: torch.Tensor | None = None) -> torch.Tensor:
+    """partials fp32 [S, M, H]; residual <- bf16(bf16(sum_s partials) + residual) in place; returns the norm."""
+    _dev(partials, "partials")
+    assert partials.dim() == 3 and partials.is_contiguous() and partials.dtype == torch.float32
+    s, m, h = partials.shape
+    assert residual.shape == (m, h) and residual.is_contiguous() and residual.dtype == torch.bfloat16
+    if out is None:
+        out = torch.empty_like(residual)
+    _check(lib().nvl_add_rmsnorm_splitk(partials.data_ptr(), s, residual.data_ptr(), weight.data_ptr(), out.data_ptr(),
+                                        m, h, eps, _stream()))
+    return out
+
 
 
 def rope_neox(positions: torch.Tensor, cos_sin: torch.Tensor, x: torch.Tensor,

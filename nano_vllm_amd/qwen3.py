@@ -8,7 +8,10 @@ is arranged for MI355X:
    add+RMSNorm -> gate_up GEMM -> SiLU*mul -> down GEMM (+all-reduce)
 
 i.e. 10 launches per layer instead of the reference's 13 (each dependent kernel boundary is
-~1.5 us on this chip even inside a hipGraph — MI355X_MICROARCH.md "boundary").
+~1.5 us on this chip even inside a hipGraph — MI355X_MICROARCH.md "boundary"). On decode-sized
+batches (<= 256 rows, TP=1) the GEMMs are the hand-written skinny kernels (nvl_linear_decode):
+SiLU*mul becomes the gate_up epilogue and o/down emit fp32 split-K partials that the next
+add+RMSNorm sums in its prologue — 9 launches per layer.
 """
 from __future__ import annotations
 
@@ -43,7 +46,7 @@ class Qwen3Attention(nn.Module):
         qw = self.q_norm.weight if self.has_qk_norm else None
         kw = self.k_norm.weight if self.has_qk_norm else None
         o = self.attn.forward_fused(qkv, positions, qw, kw, self.eps, self.rotary_emb.cos_sin_cache)
-        return self.o_proj(o.view(o.shape[0], -1))
+        return self.o_proj.forward_decode(o.view(o.shape[0], -1))
 
 
 class Qwen3MLP(nn.Module):
@@ -56,7 +59,7 @@ class Qwen3MLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+        return self.down_proj.forward_decode(self.gate_up_proj.forward_silu(x))
 
 
 class Qwen3DecoderLayer(nn.Module):

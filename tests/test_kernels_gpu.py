@@ -78,6 +78,81 @@ def test_silu_mul(ops, rows, inter):
 
 
 # ------------------------------------------------------------------------------------------
+# skinny decode linears (nvl_linear_decode): oracle = fp32 GEMM rounded where the reference's bf16
+# F.linear rounds (layers/linear.py:54-156), then the reference's SiluAndMul / add-RMSNorm on top.
+LINEAR_SHAPES = [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (512, 256), (2048, 4096)]
+
+
+def _close_to_rounded(y, acc, atol=2e-5):
+    """y (bf16) is the fp32 value `acc` rounded to bf16, up to fp32 summation-order noise: within one
+    bf16 spacing of acc (2^-8 relative) plus an absolute floor for near-cancelled sums (where an ulp
+    count is meaningless)."""
+    err = (y.cpu().float() - acc).abs()
+    return bool((err <= acc.abs() * 2.0 ** -8 + atol).all())
+
+
+def _lin_inputs(m, n, k, seed):
+    x = (torch.randn(m, k, generator=g(seed)) * 0.5).to(BF16)
+    w = (torch.randn(n, k, generator=g(seed + 1)) * 0.05).to(BF16)
+    return x, w, x.float() @ w.float().t()
+
+
+@pytest.mark.parametrize("m", [1, 7, 16, 131, 144, 256, 300])
+@pytest.mark.parametrize("n,k", LINEAR_SHAPES)
+def test_linear_decode_bf16(ops, m, n, k):
+    x, w, acc = _lin_inputs(m, n, k, 20)
+    assert ops.linear_decode_splits(m, n, k, ops.LINEAR_BF16) == 1
+    y = ops.linear_decode(dev(x), dev(w), ops.LINEAR_BF16)
+    assert y.shape == (m, n) and _close_to_rounded(y, acc)
+    assert float((ref.bf16_ulp_diff(y.cpu(), acc.to(BF16)) > 0).float().mean()) < 0.01   # order-of-summation flips only
+
+
+@pytest.mark.parametrize("m", [1, 16, 131, 144, 256, 300])
+@pytest.mark.parametrize("n,k", [(6144, 1024), (512, 256), (24576, 4096)])
+def test_linear_decode_silu(ops, m, n, k):
+    """gate|up projection with SiluAndMul as the epilogue (models/qwen3.py:90-113, activation.py:8-11)."""
+    x, w, acc = _lin_inputs(m, n, k, 22)
+    y = ops.linear_decode(dev(x), dev(w), ops.LINEAR_SILU)
+    want = ref.silu_and_mul(acc.to(BF16))
+    # the GEMM output may be 1 ulp off before the activation: allow 2 ulp after it, and check closeness
+    assert y.shape == (m, n // 2)
+    d = (y.cpu().float() - want.float()).abs()
+    assert float(d.max()) <= 2e-2 * float(want.float().abs().max())
+    assert float((ref.bf16_ulp_diff(y.cpu(), want) > 1).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("m", [1, 16, 131, 144, 256, 300])
+@pytest.mark.parametrize("n,k", [(1024, 2048), (1024, 3072), (4096, 12288), (512, 256)])
+def test_linear_decode_partials_into_add_rmsnorm(ops, m, n, k):
+    """o_proj / down_proj as fp32 split-K partials + the fused slab-sum/add/RMSNorm consumer."""
+    x, w, acc = _lin_inputs(m, n, k, 24)
+    splits = ops.linear_decode_splits(m, n, k, ops.LINEAR_PARTIAL)
+    assert splits >= 1
+    parts = ops.linear_decode(dev(x), dev(w), ops.LINEAR_PARTIAL)
+    assert parts.shape == (splits, m, n) and parts.dtype == torch.float32
+    s = parts.sum(0).cpu()
+    assert float((s - acc).abs().max()) <= 1e-4 * float(acc.abs().max()) + 1e-5
+    r = (torch.randn(m, n, generator=g(26)) * 2).to(BF16)
+    wn = (1 + 0.1 * torch.randn(n, generator=g(27))).to(BF16)
+    gemm_bf16 = parts.sum(0).to(BF16).cpu()          # the rounding point of the bf16 GEMM it replaces
+    y_ref, r_ref = ref.add_rms_forward(gemm_bf16, r, wn, 1e-6)
+    dr = dev(r.clone())
+    y = ops.add_rmsnorm_splitk(parts, dr, dev(wn), 1e-6)
+    assert float((ref.bf16_ulp_diff(dr.cpu(), r_ref) > 0).float().mean()) < 1e-3   # slab-sum order: rare 1-ulp flips
+    assert max_ulp(dr, r_ref) <= 1 and max_ulp(y, y_ref) <= 2
+
+
+def test_linear_decode_unsupported_shapes_are_reported(ops):
+    assert ops.linear_decode_splits(16, 4096, 1000, ops.LINEAR_BF16) == 0      # K not a multiple of 256
+    assert ops.linear_decode_splits(16, 4096, 128, ops.LINEAR_BF16) == 0       # K < 256
+    assert ops.linear_decode_splits(16, 4100, 1024, ops.LINEAR_BF16) == 0      # N not a multiple of 16
+    x = torch.zeros(16, 1000, dtype=BF16, device="cuda")
+    w = torch.zeros(4096, 1000, dtype=BF16, device="cuda")
+    with pytest.raises(ops.NvlError):
+        ops.linear_decode(x, w, ops.LINEAR_BF16)
+
+
+# ------------------------------------------------------------------------------------------
 def test_rope_bit_exact(ops):
     n, h, hkv = 77, 16, 8
     table = ref.rope_table(128, 4096, 1e6)

@@ -1,0 +1,77 @@
+"""Skinny decode-linear micro-benchmark + correctness vs an fp32 reference; prints one JSON line."""
+import json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.nn.functional as F
+from nano_vllm_amd import ops
+ops.load_library()
+BF16 = torch.bfloat16
+res = {}
+
+
+def timeit(fn, iters=50, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e3  # us
+
+
+def graph_time(fn, reps=20, iters=20):
+    """Per-call time inside a hipGraph of `reps` back-to-back calls (what the decode step sees)."""
+    fn(); torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    return timeit(g.replay, iters=iters, warm=3) / reps
+
+
+def check(m, n, k, mode):
+    g = torch.Generator(device="cuda").manual_seed(m * 7 + n + k + mode)
+    x = (torch.randn(m, k, device="cuda", generator=g) * 0.5).to(BF16)
+    w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).to(BF16)
+    ref = x.float() @ w.float().t()
+    if mode == 0:
+        out = ops.linear_decode(x, w, 0).float()
+        want = ref.to(BF16).float()
+    elif mode == 1:
+        out = ops.linear_decode(x, w, 1).float()
+        gte, up = ref[:, : n // 2].to(BF16).float(), ref[:, n // 2:].to(BF16).float()
+        want = (F.silu(gte) * up).to(BF16).float()
+    else:
+        out = ops.linear_decode(x, w, 2).sum(0)
+        want = ref
+    err = (out - want).abs().max().item()
+    return err / want.abs().max().item()
+
+
+shapes = [("qkv", 4096, 1024, 0), ("o", 1024, 2048, 2), ("gate_up", 6144, 1024, 1), ("down", 1024, 3072, 2)]
+res["relerr"] = {}
+for name, n, k, mode in shapes:
+    for m in (1, 16, 131, 144, 256, 300, 512):
+        res["relerr"][f"{name}_m{m}"] = check(m, n, k, mode)
+res["relerr_max"] = max(res["relerr"].values())
+
+res["time_us"] = {}
+for m in (16, 32, 64, 96, 144, 208, 256, 512):
+    for name, n, k, mode in shapes:
+        # rotate over several weight copies so the weights come from HBM like in the real step
+        ws = [(torch.randn(n, k, device="cuda") * 0.05).to(BF16) for _ in range(24)]
+        x = torch.randn(m, k, device="cuda").to(BF16)
+        outs = ops.linear_decode(x, ws[0], mode)
+        def ours():
+            for w in ws:
+                ops.linear_decode(x, w, mode, out=outs)
+        def blas():
+            for w in ws:
+                F.linear(x, w)
+        t_ours = graph_time(ours, reps=1) / len(ws)
+        t_blas = graph_time(blas, reps=1) / len(ws)
+        res["time_us"][f"{name}_m{m}"] = [round(t_ours, 2), round(t_blas, 2), round(n * k * 2 / t_ours / 1e3, 1)]
+print(json.dumps(res))

@@ -25,6 +25,8 @@ benchprof)
   f=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv && head -12 $OUT/bench_kernel_stats.csv | cut -c1-200;;
 probe)
   timeout 600 python tools/gpu_probe.py > $OUT/probe.log 2>&1; cp gpurun_out/probe.json $OUT/ 2>/dev/null; tail -3 $OUT/probe.log;;
+gemm)
+  timeout 600 python tools/gemm_bench.py > $OUT/gemm_bench.json 2> $OUT/gemm_bench.err; echo "gemm rc=$?"; tail -c 1500 $OUT/gemm_bench.err; cat $OUT/gemm_bench.json;;
 replay)
   timeout 600 python tools/attn_replay.py > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
 *) echo "unknown step $w";;
