@@ -201,7 +201,7 @@ def roofline_replay(torch, runner, rec) -> dict:
     step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * 2 * L
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"]),
-            "kernel": f"decode_stream_kernel<{hq // hkv}> (nvl_paged_attn_decode)",
+            "kernel": f"decode_stream_kernel<{hq // hkv}> + decode_stream_combine_kernel (nvl_paged_attn_decode)",
             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],
             "launches_timed": r["launches_timed"], "decode_steps_in_pass": rec["steps"],
             "kv_bytes_read_in_pass": step_bytes, "frac_of_measured_achievable_6.29TBps": achieved / 6290.0}

@@ -180,6 +180,30 @@ int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
                           void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* Decode-step fusion of the three reference launches that precede the attention
+ * call on a decode step — q/k RMSNorm (models/qwen3.py:82-84), rotary embedding
+ * (:85) and the KV-cache store (layers/attention.py:63) — into the attention
+ * kernel itself. qkv: the raw qkv GEMM output [batch, (Hq + 2*Hkv)*128] (q | k | v),
+ * token stride qkv_tok_stride. Sequence b's new token is at position
+ * context_lens[b] - 1 and is stored at the slot the block table gives for that
+ * position (what engine/model_runner.py:176-181 puts in positions / slot_mapping);
+ * rows with context_lens[b] == 0 are padding: nothing is stored, output row zero.
+ * Same numerics as nvl_qknorm_rope_kvstore followed by nvl_paged_attn_decode
+ * (q and k rounded to bf16 after the norm and again after the rotation). The
+ * caches are written (one K and one V row per (sequence, kv-head)). */
+int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stride,
+                                const void* q_norm_w, const void* k_norm_w, float eps,
+                                const float* cos_sin, int64_t max_pos,
+                                void* k_cache, void* v_cache,
+                                const int32_t* block_tables, int64_t bt_stride,
+                                const int32_t* context_lens,
+                                void* out,
+                                int64_t batch, int num_q_heads, int num_kv_heads,
+                                int block_size, int64_t num_blocks, int64_t max_context,
+                                float softmax_scale,
+                                void* workspace, size_t workspace_bytes,
+                                void* stream);
+
 /* ---- Varlen causal prefill attention (MFMA) ----------------------------------
  * Replaces flash_attn_varlen_func as called at layers/attention.py:67-70:
  * packed variable-length causal attention, mask bottom-right aligned (query i

@@ -19,7 +19,16 @@
 // packed v_dot2c_f32_bf16 and are summed over the 16 lanes of a DPP row (row_ror); softmax
 // max/sum use wave shuffles; P is rounded to bf16 before P.V (flash-attn convention), fp32
 // accumulation. All G = Hq/Hkv query heads of a group are served from one K/V read.
+//
+// FUSED variant (nvl_paged_attn_decode_fused): the decode step's q/k-RMSNorm -> RoPE -> KV-cache
+// store (models/qwen3.py:82-85 + layers/attention.py:63, a separate ~5 us launch per layer) is
+// folded in. Every wave norms+rotates the q heads it needs straight from the qkv GEMM output
+// (position = context_len - 1); the ONE wave that owns the last tile of a (sequence, kv-head)
+// norms+rotates the new token's k, writes k and v into their cache slot (derived from the block
+// table) and substitutes them for that row of its register tile — the row is never read back
+// from HBM inside this launch, so there is no intra-launch dependency to order.
 #include "common.h"
+#include "rope_common.h"
 
 namespace {
 
@@ -84,12 +93,21 @@ __device__ __forceinline__ u32x4_t load16_nt(const bf16_t* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
 }
 
-template <int G>
-__global__ __launch_bounds__(256) void decode_stream_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+struct FusedArgs {              // only read by the FUSED instantiation
+  int64_t qkv_tok_stride;
+  const bf16_t* q_norm_w;
+  const bf16_t* k_norm_w;
+  const float* cos_sin;
+  int64_t max_pos;
+  float eps;
+};
+
+template <int G, bool FUSED>
+__global__ __launch_bounds__(256, G == 4 ? 2 : 1) void decode_stream_kernel(   // G = 4: stay within 256 VGPRs
+    const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, const int32_t* __restrict__ ctx,
     float* __restrict__ part_o, float* __restrict__ part_ml, int* __restrict__ meta, int batch, int hkv,
-    int block_size, int slots, float scale_log2e) {
+    int block_size, int slots, float scale_log2e, FusedArgs fa) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int* wsum = reinterpret_cast<int*>(smem_raw);
   int* pre = wsum + kWaves;  // tile prefix [batch + 1]
@@ -122,10 +140,32 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(
     const int run = (int)min((int64_t)(nb - t0), g1 - g);
     const int len = ctx[b];
 
-    u32x4_t qf[G];
+    // Segment prologue: q rows (FUSED: plus norm weights, the cos/sin row, the new token's raw k / v).
+    u32x4_t qf[G], rawq[G];
+    u32x4_t knew = {0u, 0u, 0u, 0u}, vnew = {0u, 0u, 0u, 0u}, wq = {0u, 0u, 0u, 0u}, wk = {0u, 0u, 0u, 0u};
+    RopeRegs rr = {};
+    const bool owns_last = FUSED && (t0 + run == nb);             // this wave processes the tile of token len-1
+    if constexpr (FUSED) {
+      // q is the raw qkv GEMM row [q heads | k heads | v heads]; the new token sits at position len-1
+      int64_t pos = len - 1;
+      pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
+      const bf16_t* row = q + (int64_t)b * fa.qkv_tok_stride;
 #pragma unroll
-    for (int gg = 0; gg < G; ++gg)
-      qf[gg] = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)b * hq + h * G + gg) * 128 + sub * 8);
+      for (int gg = 0; gg < G; ++gg) rawq[gg] = *reinterpret_cast<const u32x4_t*>(row + (h * G + gg) * 128 + sub * 8);
+      rr = load_rope_regs(fa.cos_sin + pos * 128, sub);
+      if (fa.q_norm_w != nullptr) {
+        wq = *reinterpret_cast<const u32x4_t*>(fa.q_norm_w + sub * 8);
+        wk = *reinterpret_cast<const u32x4_t*>(fa.k_norm_w + sub * 8);
+      }
+      if (owns_last) {
+        knew = *reinterpret_cast<const u32x4_t*>(row + (hq + h) * 128 + sub * 8);
+        vnew = *reinterpret_cast<const u32x4_t*>(row + (hq + hkv + h) * 128 + sub * 8);
+      }
+    } else {
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg)
+        rawq[gg] = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)b * hq + h * G + gg) * 128 + sub * 8);
+    }
     float m[G], l[G], o[G][8];
 #pragma unroll
     for (int gg = 0; gg < G; ++gg) {
@@ -135,23 +175,58 @@ __global__ __launch_bounds__(256) void decode_stream_kernel(
       for (int j = 0; j < 8; ++j) o[gg][j] = 0.f;
     }
 
-    for (int ti = t0; ti < t0 + run; ++ti) {
+    u32x4_t kd[kLoads], vd[kLoads];
+    auto issue_tile = [&](int ti) {
       const int t = ti * kTile;
       const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
       const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
       const bf16_t* kp = kc + base;
       const bf16_t* vp = vc + base;
-      u32x4_t kd[kLoads], vd[kLoads];
 #pragma unroll
       for (int i = 0; i < kLoads; ++i) kd[i] = load16_nt(kp + i * 4 * 128);
 #pragma unroll
       for (int i = 0; i < kLoads; ++i) vd[i] = load16_nt(vp + i * 4 * 128);
-      __builtin_amdgcn_sched_barrier(0);  // all 16 loads in flight before the first use
+    };
+    if constexpr (FUSED) {
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg)
+        qf[gg] = norm_rope_head_regs(rawq[gg], fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
+      if (owns_last) {
+        knew = norm_rope_head_regs(knew, fa.k_norm_w != nullptr, wk, fa.eps, rr, sub);
+        const int tl = len - 1;
+        if (rq == 0) {                                             // one 256-byte row each, for later steps
+          const int blk = block_tables[(int64_t)b * bt_stride + tl / block_size];
+          const int64_t dst = (((int64_t)blk * hkv + h) * block_size + (tl % block_size)) * 128 + sub * 8;
+          *reinterpret_cast<u32x4_t*>(kc + dst) = knew;
+          *reinterpret_cast<u32x4_t*>(vc + dst) = vnew;
+        }
+        // The new token enters the online softmax HERE, as the first key of this wave's segment
+        // (m = its score, l = 1, O = v; P = bf16(2^0) = 1): its cache row is written above but never
+        // read back inside this launch — the tile loop masks row len-1.
+        float vf[8];
+        unpack8(vnew, vf);
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) {
+          m[gg] = row16_allreduce_sum(dot8(knew, qf[gg])) * scale_log2e;
+          l[gg] = rq == 0 ? 1.f : 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[gg][j] = rq == 0 ? vf[j] : 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) qf[gg] = rawq[gg];
+    }
+    const int len_cached = FUSED ? len - 1 : len;    // rows of the cache that hold valid K/V for this launch
 
+    for (int ti = t0; ti < t0 + run; ++ti) {
+      const int t = ti * kTile;
+      issue_tile(ti);
+      __builtin_amdgcn_sched_barrier(0);  // all 16 loads in flight before the first use
       float s[G][kLoads];
 #pragma unroll
       for (int i = 0; i < kLoads; ++i) {
-        const bool valid = (t + i * 4 + rq) < len;
+        const bool valid = (t + i * 4 + rq) < len_cached;
 #pragma unroll
         for (int gg = 0; gg < G; ++gg) {
           const float d = row16_allreduce_sum(dot8(kd[i], qf[gg]));
@@ -258,10 +333,10 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
 
 inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 2; }
 
-template <int G>
-int launch_decode_stream(const void* q, const void* kc, const void* vc, const int32_t* bt, int64_t bt_stride,
+template <int G, bool FUSED>
+int launch_decode_stream(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride,
                          const int32_t* ctx, void* out, int64_t batch, int hkv, int block_size, int64_t max_context,
-                         float scale, void* workspace, hipStream_t s) {
+                         float scale, void* workspace, hipStream_t s, const FusedArgs& fa) {
   const int hq = hkv * G;
   const int slots = stream_slots(max_context);
   float* part_o = (float*)workspace;
@@ -272,7 +347,7 @@ int launch_decode_stream(const void* q, const void* kc, const void* vc, const in
   if (cus == 0) {
     cus = nvl_device_cu_count();
     int n = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, decode_stream_kernel<G>, 256, lds) != hipSuccess || n < 1) n = 2;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, decode_stream_kernel<G, FUSED>, 256, lds) != hipSuccess || n < 1) n = 2;
     per_cu = n > 4 ? 4 : n;
   }
   int64_t grid = (int64_t)cus * per_cu;
@@ -280,9 +355,9 @@ int launch_decode_stream(const void* q, const void* kc, const void* vc, const in
   const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
   if (grid > max_wg) grid = max_wg;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((decode_stream_kernel<G>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
-                     (const bf16_t*)kc, (const bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (int)batch, hkv,
-                     block_size, slots, scale * 1.4426950408889634f);
+  hipLaunchKernelGGL((decode_stream_kernel<G, FUSED>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
+                     (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (int)batch, hkv,
+                     block_size, slots, scale * 1.4426950408889634f, fa);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
                      meta, ctx, (bf16_t*)out, hq, hkv, slots);
   return nvl_check_launch("nvl_paged_attn_decode");
@@ -295,37 +370,78 @@ extern "C" size_t nvl_paged_attn_decode_workspace_bytes(int64_t max_batch, int n
   return (size_t)max_batch * num_q_heads * (stream_slots(max_context) * 130 * sizeof(float) + sizeof(int));
 }
 
-extern "C" int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
-                                     const int32_t* block_tables, int64_t bt_stride, const int32_t* context_lens,
-                                     void* out, int64_t batch, int num_q_heads, int num_kv_heads, int block_size,
-                                     int64_t num_blocks, int64_t max_context, float softmax_scale, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
-  NVL_REQUIRE(q && k_cache && v_cache && block_tables && context_lens && out && workspace,
-              "nvl_paged_attn_decode: null pointer");
-  NVL_REQUIRE(batch >= 0 && batch <= 32768, "nvl_paged_attn_decode: batch=%lld out of range [0, 32768]", (long long)batch);
-  NVL_REQUIRE(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "nvl_paged_attn_decode: Hq=%d not a multiple of Hkv=%d", num_q_heads, num_kv_heads);
-  NVL_REQUIRE(block_size > 0 && block_size % kTile == 0, "nvl_paged_attn_decode: block_size=%d must be a multiple of %d", block_size, kTile);
-  NVL_REQUIRE(num_blocks > 0 && max_context > 0, "nvl_paged_attn_decode: bad cache geometry");
-  NVL_REQUIRE(bt_stride * (int64_t)block_size >= max_context, "nvl_paged_attn_decode: block table (stride %lld) narrower than max_context=%lld", (long long)bt_stride, (long long)max_context);
+namespace {
+
+int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* block_tables, int64_t bt_stride,
+                  const int32_t* context_lens, void* out, int64_t batch, int num_q_heads, int num_kv_heads,
+                  int block_size, int64_t num_blocks, int64_t max_context, float softmax_scale, void* workspace,
+                  size_t workspace_bytes, void* stream, const FusedArgs* fa, const char* who) {
+  NVL_REQUIRE(q && k_cache && v_cache && block_tables && context_lens && out && workspace, "%s: null pointer", who);
+  NVL_REQUIRE(batch >= 0 && batch <= 32768, "%s: batch=%lld out of range [0, 32768]", who, (long long)batch);
+  NVL_REQUIRE(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "%s: Hq=%d not a multiple of Hkv=%d", who, num_q_heads, num_kv_heads);
+  NVL_REQUIRE(block_size > 0 && block_size % kTile == 0, "%s: block_size=%d must be a multiple of %d", who, block_size, kTile);
+  NVL_REQUIRE(num_blocks > 0 && max_context > 0, "%s: bad cache geometry", who);
+  NVL_REQUIRE(bt_stride * (int64_t)block_size >= max_context, "%s: block table (stride %lld) narrower than max_context=%lld", who, (long long)bt_stride, (long long)max_context);
   NVL_REQUIRE(((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out | (uintptr_t)workspace) % 16 == 0,
-              "nvl_paged_attn_decode: pointers must be 16-byte aligned");
+              "%s: pointers must be 16-byte aligned", who);
   if (batch == 0) return NVL_OK;
   const int G = num_q_heads / num_kv_heads;
   const size_t need = nvl_paged_attn_decode_workspace_bytes(batch, num_q_heads, max_context);
-  NVL_REQUIRE(workspace_bytes >= need, "nvl_paged_attn_decode: workspace %zu B < required %zu B", workspace_bytes, need);
+  NVL_REQUIRE(workspace_bytes >= need, "%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
-#define NVL_DECODE_CASE(GG)                                                                                   \
-  case GG:                                                                                                    \
-    return launch_decode_stream<GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,  \
-                                    num_kv_heads, block_size, max_context, softmax_scale, workspace, s);
+  const FusedArgs none = {};
+#define NVL_DECODE_CASE(GG)                                                                                        \
+  case GG:                                                                                                         \
+    return fa ? launch_decode_stream<GG, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,   \
+                                               batch, num_kv_heads, block_size, max_context, softmax_scale,       \
+                                               workspace, s, *fa)                                                 \
+              : launch_decode_stream<GG, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
+                                                batch, num_kv_heads, block_size, max_context, softmax_scale,      \
+                                                workspace, s, none);
   switch (G) {
     NVL_DECODE_CASE(1)
     NVL_DECODE_CASE(2)
     NVL_DECODE_CASE(4)
     NVL_DECODE_CASE(8)
     default:
-      nvl_set_error("nvl_paged_attn_decode: unsupported group size Hq/Hkv=%d (supported 1,2,4,8)", G);
+      nvl_set_error("%s: unsupported group size Hq/Hkv=%d (supported 1,2,4,8)", who, G);
       return NVL_EUNSUPPORTED;
   }
 #undef NVL_DECODE_CASE
+}
+
+}  // namespace
+
+extern "C" int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
+                                     const int32_t* block_tables, int64_t bt_stride, const int32_t* context_lens,
+                                     void* out, int64_t batch, int num_q_heads, int num_kv_heads, int block_size,
+                                     int64_t num_blocks, int64_t max_context, float softmax_scale, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  return decode_common(q, const_cast<void*>(k_cache), const_cast<void*>(v_cache), block_tables, bt_stride,
+                       context_lens, out, batch, num_q_heads, num_kv_heads, block_size, num_blocks, max_context,
+                       softmax_scale, workspace, workspace_bytes, stream, nullptr, "nvl_paged_attn_decode");
+}
+
+extern "C" int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stride, const void* q_norm_w,
+                                           const void* k_norm_w, float eps, const float* cos_sin, int64_t max_pos,
+                                           void* k_cache, void* v_cache, const int32_t* block_tables,
+                                           int64_t bt_stride, const int32_t* context_lens, void* out, int64_t batch,
+                                           int num_q_heads, int num_kv_heads, int block_size, int64_t num_blocks,
+                                           int64_t max_context, float softmax_scale, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  const char* who = "nvl_paged_attn_decode_fused";
+  NVL_REQUIRE(cos_sin && max_pos > 0, "%s: rope table required", who);
+  NVL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "%s: q/k norm weights must both be set or both NULL", who);
+  NVL_REQUIRE(qkv_tok_stride % 8 == 0 && qkv_tok_stride >= (int64_t)(num_q_heads + 2 * num_kv_heads) * 128, "%s: bad qkv stride", who);
+  NVL_REQUIRE(((uintptr_t)q_norm_w | (uintptr_t)k_norm_w | (uintptr_t)cos_sin) % 16 == 0, "%s: pointers must be 16-byte aligned", who);
+  FusedArgs fa;
+  fa.qkv_tok_stride = qkv_tok_stride;
+  fa.q_norm_w = (const bf16_t*)q_norm_w;
+  fa.k_norm_w = (const bf16_t*)k_norm_w;
+  fa.cos_sin = cos_sin;
+  fa.max_pos = max_pos;
+  fa.eps = eps;
+  return decode_common(qkv, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch, num_q_heads,
+                       num_kv_heads, block_size, num_blocks, max_context, softmax_scale, workspace, workspace_bytes,
+                       stream, &fa, who);
 }

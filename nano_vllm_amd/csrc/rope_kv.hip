@@ -5,46 +5,12 @@
 // Reference semantics: layers/rotary_embedding.py:6-14,37-48; layers/attention.py:10-40;
 // models/qwen3.py:82-85 (q_norm/k_norm before the rotation).
 #include "common.h"
+#include "rope_common.h"
 
 // Keep mul/add separately rounded (as the fp32 oracle does): no FMA contraction in this file.
 #pragma clang fp contract(off)
 
 namespace {
-
-// Rotate the 8 values held by this lane. `v` are fp32 views of bf16 inputs; cs points at
-// cos_sin[pos][0]. Returns fp32 results (caller rounds).
-__device__ __forceinline__ void rope8(const float* v, const float* __restrict__ cs, int sub, float* o) {
-  const int f0 = (sub & 7) * 8;  // frequency index of element 0
-  const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(cs + f0);
-  const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(cs + f0 + 4);
-  const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(cs + 64 + f0);
-  const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(cs + 64 + f0 + 4);
-  const bool upper = sub >= 8;  // this lane holds x2 (elements 64..127)
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float c = i < 4 ? c0[i] : c1[i - 4];
-    const float s = i < 4 ? s0[i] : s1[i - 4];
-    const float other = row16_ror8(v[i]);
-    // lower: y1 = x1*c - x2*s ; upper: y2 = x2*c + x1*s   (rotary_embedding.py:12-13)
-    const float a = v[i] * c;
-    const float b = other * s;
-    o[i] = upper ? a + b : a - b;
-  }
-}
-
-// RMSNorm over one 128-wide head held by 16 lanes; result rounded to bf16 (as the reference
-// materialises q/k between the norm graph and the rope graph).
-__device__ __forceinline__ void headnorm8(float* v, const bf16_t* __restrict__ w, int sub, float eps) {
-  float ss = 0.f;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
-  ss = row16_allreduce_sum(ss);
-  const float rstd = rsqrtf(ss * (1.f / 128.f) + eps);
-  float wf[8];
-  unpack8(*reinterpret_cast<const u32x4_t*>(w + sub * 8), wf);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) v[i] = round_bf16(v[i] * rstd * wf[i]);
-}
 
 __device__ __forceinline__ int64_t cache_row_offset(int64_t slot, int head, int num_kv_heads, int block_size) {
   const int64_t blk = slot / block_size;

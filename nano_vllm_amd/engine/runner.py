@@ -197,8 +197,9 @@ class ModelRunner:
         self.tokens_dev = torch.zeros(max(mb, ns), dtype=torch.int64, device=self.device)
         self.tokens_host = torch.zeros(max(mb, ns), dtype=torch.int64, device="cpu", pin_memory=True)
         ws_bytes = ops.paged_attn_decode_workspace_bytes(mb, self.geo["heads"], cfg.max_model_len)
-        self.decode_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
-        self.decode_ws_b = torch.empty(ws_bytes, dtype=torch.uint8, device=self.device)
+        # zeroed once: the kernel's arrival counters live in it and are left at zero by every launch
+        self.decode_ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
+        self.decode_ws_b = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
         self.hidden_out = (torch.zeros(mb, self.geo["hidden"], dtype=torch.bfloat16, device=self.device)
                            if self.world_size > 1 else None)
         self.step_count = 0

@@ -16,6 +16,7 @@ There is no eager-PyTorch fallback for the hot ops: tensors must live on the GPU
 """
 from __future__ import annotations
 
+import os
 from functools import lru_cache
 
 import torch
@@ -86,6 +87,10 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, de
     return _rope_singleton(head_size, rotary_dim, max_position, float(base), str(device))
 
 
+# NVL_FUSED_DECODE=0 keeps the separate q/k-norm+RoPE+KV-store launch on decode steps (A/B measurements)
+_FUSED_DECODE = os.environ.get("NVL_FUSED_DECODE", "1") != "0"
+
+
 class Attention(nn.Module):
     """Paged attention. `k_cache` / `v_cache` are injected by the runner; layout
     [num_blocks, num_kv_heads, block_size, 128] (head-major — see include/nvl.h)."""
@@ -111,6 +116,16 @@ class Attention(nn.Module):
         n = qkv.shape[0]
         hq, hkv = self.num_heads, self.num_kv_heads
         has_cache = self.k_cache.numel() > 0
+        if not ctx.is_prefill and has_cache and _FUSED_DECODE:
+            # decode step: norm + rope + KV store happen inside the attention kernel (position and slot
+            # of each sequence's new token follow from context_lens / block_tables)
+            ws = ctx.decode_workspace
+            max_context = ctx.max_context or ctx.block_tables.shape[1] * self.k_cache.shape[2]
+            if ws is None:
+                ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(n, hq, max_context), dtype=torch.uint8,
+                                 device=qkv.device)
+            return ops.paged_attn_decode_fused(qkv, q_norm_w, k_norm_w, eps, rope_table, self.k_cache, self.v_cache,
+                                               ctx.block_tables, ctx.context_lens, hq, self.scale, max_context, ws)
         q = torch.empty((n, hq, 128), dtype=qkv.dtype, device=qkv.device)
         need_k = ctx.is_prefill and ctx.block_tables is None      # non-paged prefill reads packed K
         k = torch.empty((n, hkv, 128), dtype=qkv.dtype, device=qkv.device) if need_k else None
@@ -129,7 +144,7 @@ class Attention(nn.Module):
         ws = ctx.decode_workspace
         max_context = ctx.max_context or ctx.block_tables.shape[1] * self.k_cache.shape[2]
         if ws is None:
-            ws = torch.empty(ops.paged_attn_decode_workspace_bytes(q.shape[0], self.num_heads, max_context),
+            ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(q.shape[0], self.num_heads, max_context),
                              dtype=torch.uint8, device=q.device)
         return ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens, self.scale,
                                      max_context, ws)

@@ -38,6 +38,9 @@ SIGNATURES = {
     "nvl_paged_attn_decode_workspace_bytes": (c_size_t, [c_int64, c_int, c_int64]),
     "nvl_paged_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                       c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
+    "nvl_paged_attn_decode_fused": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p,
+                                            c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                            c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
     "nvl_attn_prefill_varlen": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                         c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
                                         c_void_p]),
@@ -252,6 +255,28 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
                                        block_tables.stride(0), context_lens.data_ptr(), out.data_ptr(), b, hq,
                                        k_cache.shape[1], k_cache.shape[2], k_cache.shape[0], max_context, scale,
                                        workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+    return out
+
+
+def paged_attn_decode_fused(qkv: torch.Tensor, q_norm_w, k_norm_w, eps: float, cos_sin: torch.Tensor,
+                            k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
+                            context_lens: torch.Tensor, num_q_heads: int, scale: float, max_context: int,
+                            workspace: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Decode step in one launch: q/k-norm + RoPE (position = context_len - 1) + KV-cache store of the
+    new token + paged attention. qkv: raw qkv GEMM output [B, (Hq + 2*Hkv)*128]."""
+    _dev(qkv, "qkv")
+    assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.dtype == torch.bfloat16
+    assert block_tables.dtype == torch.int32 and context_lens.dtype == torch.int32 and block_tables.stride(1) == 1
+    assert cos_sin.dtype == torch.float32 and cos_sin.is_contiguous()
+    b = qkv.shape[0]
+    if out is None:
+        out = torch.empty((b, num_q_heads, 128), dtype=qkv.dtype, device=qkv.device)
+    _check(lib().nvl_paged_attn_decode_fused(
+        qkv.data_ptr(), qkv.stride(0), q_norm_w.data_ptr() if q_norm_w is not None else None,
+        k_norm_w.data_ptr() if k_norm_w is not None else None, eps, cos_sin.data_ptr(), cos_sin.shape[0],
+        k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(), block_tables.stride(0),
+        context_lens.data_ptr(), out.data_ptr(), b, num_q_heads, k_cache.shape[1], k_cache.shape[2], k_cache.shape[0],
+        max_context, scale, workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
     return out
 
 

@@ -259,7 +259,7 @@ def test_paged_attn_decode(ops, hq, hkv, lens):
     max_ctx = 4096
     btw = torch.full((b, max_ctx // bs), -1, dtype=torch.int32)
     btw[:, : bt.shape[1]] = bt
-    ws = torch.empty(ops.paged_attn_decode_workspace_bytes(b, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, max_ctx), dtype=torch.uint8, device="cuda")
     o = ops.paged_attn_decode(dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(btw), dev(ctx), scale,
                               max_ctx, ws)
     err = (o.cpu().float() - o_ref.float()).abs().max().item()
@@ -267,6 +267,69 @@ def test_paged_attn_decode(ops, hq, hkv, lens):
     for i, n in enumerate(lens):
         if n == 0:
             assert torch.count_nonzero(o[i]) == 0  # padded rows produce zeros
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1)])
+@pytest.mark.parametrize("lens", [[1], [255, 256, 257, 33], [1, 100, 1023, 1024, 1025, 2048, 17, 0, 640], [4096, 3, 0, 700]])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_paged_attn_decode_fused_equals_unfused(ops, hq, hkv, lens, with_norm):
+    """nvl_paged_attn_decode_fused vs nvl_qknorm_rope_kvstore + nvl_paged_attn_decode with positions /
+    slots derived from context_lens / block_tables as the runner builds them
+    (engine/model_runner.py:172-188): both caches bit for bit; outputs to flash tolerance (the fused
+    kernel feeds the new token to the online softmax first instead of last: same math, different
+    fp32 summation order)."""
+    bs, max_ctx = 256, 4096
+    gen = g(40)
+    b = len(lens)
+    nb = [(n + bs - 1) // bs for n in lens]
+    total = sum(nb) + 3
+    kc = torch.randn(total, hkv, bs, 128, generator=gen).to(BF16)
+    vc = torch.randn(total, hkv, bs, 128, generator=gen).to(BF16)
+    perm = torch.randperm(total, generator=gen).tolist()
+    bt = torch.full((b, max_ctx // bs), -1, dtype=torch.int32)
+    c = 0
+    for s_, n in enumerate(nb):
+        for j in range(n):
+            bt[s_, j] = perm[c]
+            c += 1
+    qkv = torch.randn(b, (hq + 2 * hkv) * 128, generator=gen).to(BF16)
+    qw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16) if with_norm else None
+    kw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16) if with_norm else None
+    inv = 1.0 / (1e6 ** (torch.arange(0, 128, 2).float() / 128))
+    fr = torch.arange(max_ctx).float()[:, None] * inv[None]
+    table = torch.cat([fr.cos(), fr.sin()], -1).contiguous()
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    pos = (ctx.long() - 1).clamp(min=0)
+    slots = torch.tensor([int(bt[i, (n - 1) // bs]) * bs + (n - 1) % bs if n > 0 else -1 for i, n in enumerate(lens)],
+                         dtype=torch.int32)
+    scale = 128 ** -0.5
+    d = dict(qkv=dev(qkv), qw=dev(qw) if with_norm else None, kw=dev(kw) if with_norm else None, table=dev(table),
+             bt=dev(bt), ctx=dev(ctx))
+    # unfused
+    kc1, vc1 = dev(kc.clone()), dev(vc.clone())
+    q1 = torch.empty(b, hq, 128, dtype=BF16, device="cuda")
+    ops.qknorm_rope_kvstore(d["qkv"], dev(pos), d["qw"], d["kw"], 1e-6, d["table"], dev(slots), q1, None, kc1, vc1, hq, hkv)
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    o1 = ops.paged_attn_decode(q1, kc1, vc1, d["bt"], d["ctx"], scale, max_ctx, ws)
+    # fused
+    kc2, vc2 = dev(kc.clone()), dev(vc.clone())
+    ws2 = torch.zeros_like(ws)
+    o2 = ops.paged_attn_decode_fused(d["qkv"], d["qw"], d["kw"], 1e-6, d["table"], kc2, vc2, d["bt"], d["ctx"], hq, scale,
+                                     max_ctx, ws2)
+    torch.cuda.synchronize()
+    assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2)
+    err = float((o1.float() - o2.float()).abs().max())
+    assert err <= 1e-2 * max(1e-6, float(o1.float().abs().max()))
+    # and against the CPU oracle directly (token-major caches, flash_attn_with_kvcache semantics)
+    live = [i for i, n in enumerate(lens) if n > 0]
+    if live:
+        o_ref = ref.flash_attn_with_kvcache(q1.cpu().unsqueeze(1), ref.from_head_major(kc1.cpu()), ref.from_head_major(vc1.cpu()),
+                                            ctx, bt, scale).squeeze(1)
+        d = (o2.cpu().float()[live] - o_ref.float()[live]).abs().max()
+        assert float(d) <= 2e-2 * float(o_ref.float()[live].abs().max())
+    for i, n in enumerate(lens):
+        if n == 0:
+            assert not o2[i].any()
 
 
 def test_paged_attn_decode_large_batch(ops):
@@ -282,7 +345,7 @@ def test_paged_attn_decode_large_batch(ops):
     max_ctx = 4096
     btw = torch.full((256, max_ctx // bs), -1, dtype=torch.int32)
     btw[:, : bt.shape[1]] = bt
-    ws = torch.empty(ops.paged_attn_decode_workspace_bytes(256, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(256, hq, max_ctx), dtype=torch.uint8, device="cuda")
     o = ops.paged_attn_decode(dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(btw), dev(ctx), scale,
                               max_ctx, ws)
     err = (o.cpu().float() - o_ref.float()).abs().max().item()

@@ -66,7 +66,7 @@ def bench_decode_batches(num_seqs: int = 256, num_blocks: int = 9380, every: int
     return samples, dict(decode_steps=steps, prefill_steps=prefills, ctx_tokens=ctx_tokens, max_block=max_block)
 
 
-def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: int = 2, pool_blocks: int | None = None):
+def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: int = 2, fused: bool = False):
     """Time nvl_paged_attn_decode (main kernel + split combine) on the recorded batches.
     kv_cache: [2, L, num_blocks, Hkv, block, 128]. Block ids are folded into the cache with a
     modulo when the cache is smaller than the pool the schedule was recorded with."""
@@ -77,6 +77,12 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
     max_bs = max(n for n, _, _ in samples)
     q_all = torch.randn(max_bs, hq, 128, device=dev, dtype=torch.bfloat16)
     out = torch.empty_like(q_all)
+    if fused:       # the decode step's real entry point: raw qkv rows in, q/k-norm + RoPE + KV store inside
+        qkv_all = torch.randn(max_bs, (hq + 2 * hkv) * 128, device=dev, dtype=torch.bfloat16)
+        nw = torch.ones(128, device=dev, dtype=torch.bfloat16)
+        inv = 1.0 / (1e6 ** (torch.arange(0, 128, 2, device=dev).float() / 128))
+        fr = torch.arange(40960, device=dev).float()[:, None] * inv[None]
+        table = torch.cat([fr.cos(), fr.sin()], -1).contiguous()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     total_ms, total_bytes, launches = 0.0, 0, 0
     for n, ctx, bt in samples:
@@ -88,8 +94,12 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
         for _ in range(reps):                       # keep the last rep (caches are 100s of MB: nothing stays warm)
             start.record()
             for layer in range(L):
-                ops.paged_attn_decode(q, kv_cache[0, layer], kv_cache[1, layer], bt_d, ctx_d, scale, max_ctx, ws,
-                                      out=out[:n])
+                if fused:
+                    ops.paged_attn_decode_fused(qkv_all[:n], nw, nw, 1e-6, table, kv_cache[0, layer], kv_cache[1, layer],
+                                                bt_d, ctx_d, hq, scale, max_ctx, ws, out=out[:n])
+                else:
+                    ops.paged_attn_decode(q, kv_cache[0, layer], kv_cache[1, layer], bt_d, ctx_d, scale, max_ctx, ws,
+                                          out=out[:n])
             stop.record()
             torch.cuda.synchronize()
         total_ms += start.elapsed_time(stop)
@@ -107,6 +117,7 @@ def main():
     ap.add_argument("--hkv", type=int, default=8)
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--pool-blocks", type=int, default=9380, help="KV pool the schedule is recorded with")
+    ap.add_argument("--fused", action="store_true", help="time nvl_paged_attn_decode_fused (norm+rope+store inside)")
     args = ap.parse_args()
     import torch
     from nano_vllm_amd import ops
@@ -117,9 +128,9 @@ def main():
     kv = torch.empty(2, args.layers, nblk, args.hkv, 256, 128, dtype=torch.bfloat16, device=dev)
     for layer in range(args.layers):               # random (not zero) data: zero-filled inputs clock higher
         kv[:, layer].normal_()
-    ws = torch.empty(ops.paged_attn_decode_workspace_bytes(512, args.hq, 4096), dtype=torch.uint8, device=dev)
-    r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps)
-    r.update(stats, kernel=f"decode_stream_kernel<{args.hq // args.hkv}>", kv_blocks_used=nblk, samples=len(samples),
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(512, args.hq, 4096), dtype=torch.uint8, device=dev)
+    r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps, fused=args.fused)
+    r.update(stats, kernel=f"decode_stream_kernel<{args.hq // args.hkv}, {str(args.fused).lower()}>", kv_blocks_used=nblk, samples=len(samples),
              frac_of_8TBps=r["achieved_GBps"] / 8000.0)
     print(json.dumps(r), flush=True)
 

@@ -55,7 +55,7 @@ def case(batch, lo, hi, hq, hkv, seed=0, layers=8):
         bt[i, : nb[i]] = perm[c: c + nb[i]].to(torch.int32); c += int(nb[i])
     q = torch.randn(batch, hq, 128, device="cuda").to(BF16)
     ctx = lens.to(torch.int32).cuda(); btd = bt.cuda()
-    ws = torch.empty(ops.paged_attn_decode_workspace_bytes(batch, hq, 4096), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(batch, hq, 4096), dtype=torch.uint8, device="cuda")
     o = torch.empty_like(q)
     def fn():
         for kc, vc in caches:   # rotate over distinct caches: cold K/V like consecutive layers

@@ -94,7 +94,7 @@ def decode_case(batch, lo, hi, hq, hkv, seed=0):
     q = torch.randn(batch, hq, 128, device="cuda").to(BF16)
     ctx = lens.to(torch.int32).cuda()
     btd = bt.cuda()
-    ws = torch.empty(ops.paged_attn_decode_workspace_bytes(batch, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(batch, hq, max_ctx), dtype=torch.uint8, device="cuda")
     o = torch.empty_like(q)
     fn = lambda: ops.paged_attn_decode(q, kc, vc, btd, ctx, 128 ** -0.5, max_ctx, ws, out=o)
     t = timeit(fn, iters=30)
