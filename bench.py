@@ -196,12 +196,12 @@ def roofline_replay(torch, runner, rec) -> dict:
     from tools.attn_replay import replay
     geo = runner.geo
     hq, hkv, L = geo["heads"], geo["kv_heads"], geo["layers"]
-    r = replay(torch, runner.kv_cache, rec["samples"], hq, hkv, runner.config.max_model_len, runner.decode_ws)
+    r = replay(torch, runner.kv_cache, rec["samples"], hq, hkv, runner.config.max_model_len, runner.decode_ws, fused=True)
     achieved = r["achieved_GBps"]
     step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * 2 * L
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"]),
-            "kernel": f"decode_stream_kernel<{hq // hkv}> + decode_stream_combine_kernel (nvl_paged_attn_decode)",
+            "kernel": f"decode_stream_kernel<{hq // hkv}, fused> + decode_stream_combine_kernel (nvl_paged_attn_decode_fused: the launch the decode step makes)",
             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],
             "launches_timed": r["launches_timed"], "decode_steps_in_pass": rec["steps"],
             "kv_bytes_read_in_pass": step_bytes, "frac_of_measured_achievable_6.29TBps": achieved / 6290.0}

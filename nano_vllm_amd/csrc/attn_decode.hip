@@ -28,6 +28,7 @@
 // table) and substitutes them for that row of its register tile — the row is never read back
 // from HBM inside this launch, so there is no intra-launch dependency to order.
 #include "common.h"
+#include <stdlib.h>
 #include "rope_common.h"
 
 namespace {
@@ -348,7 +349,10 @@ int launch_decode_stream(const void* q, void* kc, void* vc, const int32_t* bt, i
     cus = nvl_device_cu_count();
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, decode_stream_kernel<G, FUSED>, 256, lds) != hipSuccess || n < 1) n = 2;
-    per_cu = n > 4 ? 4 : n;
+    // 2 workgroups (8 waves, 128 KiB of loads in flight) per CU saturate HBM; measured on the bench replay:
+    // 1 / 2 / 3 per CU = 93.3 / 89.4 / 91.1 us per launch (profiles/README.md)
+    per_cu = n > 2 ? 2 : n;
+    if (const char* e = getenv("NVL_DECODE_WGS_PER_CU")) { const int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }
   }
   int64_t grid = (int64_t)cus * per_cu;
   const int64_t max_tiles = batch * hkv * ((max_context + kTile - 1) / kTile);

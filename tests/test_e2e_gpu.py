@@ -140,3 +140,83 @@ def test_string_prompts_and_eos(tiny_ckpt):
     for o in outs:
         assert eos not in o["token_ids"][:-1]       # generation stops at the first EOS (included)
     llm.exit()
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json config 2 shapes (Qwen3-0.6B: hidden 1024, 28 layers, 16/8 heads, vocab 151,936) with
+# seeded synthetic weights. The CPU oracle runs this size at ~4 tok/s, so the oracle comparison uses a
+# small sample and the full bench-shaped workload is covered by size-independent properties.
+@pytest.fixture(scope="module")
+def ckpt_06b():
+    from nano_vllm_amd.weights import write_synthetic_checkpoint
+    path = tempfile.mkdtemp(prefix="qwen3_06b_")
+    write_synthetic_checkpoint(path, "qwen3-0.6b", with_weights=False)
+    return path
+
+
+def _oracle_weights_06b(device):
+    from nano_vllm_amd.weights import parameter_shapes, qwen3_config_dict, synth_tensor
+    cfg = qwen3_config_dict("qwen3-0.6b")
+    return cfg, {n: synth_tensor(n, s, 0, device=device).cpu() for n, s in parameter_shapes(cfg).items()}
+
+
+def test_qwen3_06b_shape_greedy_parity_vs_oracle(ckpt_06b):
+    """Full-size layers (fused decode attention G=2, skinny decode GEMMs at K=1024/2048/3072, sampler
+    over 151,936 logits): every token we pick must be the CPU oracle's argmax (or within TOL) for the
+    same history, with identical scheduling."""
+    from oracle.engine import OracleEngine
+    from oracle.model import OracleQwen3
+    prompts = _prompts(3, 20, 300, 10000, seed=21)
+    max_tokens = [6, 4, 5]
+    outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, enforce_eager=False, max_model_len=1024,
+                                num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True)
+    cfg, w = _oracle_weights_06b("cuda")
+    eng = OracleEngine(OracleQwen3(cfg, w, compiled=True), nblk, 256, max_num_seqs=8)
+    eng.keep_logits = True
+    for p, m in zip(prompts, max_tokens):
+        eng.add(p, 0.0, m, True)
+    exact = total = 0
+    worst = 0.0
+    for i, r in enumerate(rec):
+        eng.step(forced_tokens=r["tokens"])
+        o = eng.trace[-1]
+        assert o["is_prefill"] == r["prefill"] and o["tables"] == r["tables"], f"step {i}: schedule differs"
+        for row, tok in enumerate(r["tokens"]):
+            gap = float(o["logits"][row].max() - o["logits"][row, tok])
+            worst = max(worst, gap)
+            exact += gap == 0.0
+            total += 1
+    print(f"0.6B shapes: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
+    assert worst <= TOL and exact >= 0.8 * total
+
+
+def test_qwen3_06b_shape_bench_workload_properties(ckpt_06b):
+    """The bench workload's shape (ragged prompts 100-1024, ragged outputs, T=0) at a reduced sequence
+    count: (1) the captured-hipGraph engine and the eager engine pick identical tokens — same kernels,
+    padded graph rows contribute no work; (2) a second identical run reproduces them bit for bit
+    (no atomics / race-dependent summation order anywhere on the path); (3) a sequence decoded alone
+    yields the same tokens as inside the batch up to bf16 near-ties (split points of the stream-K
+    attention move with the batch): compared on its first tokens only."""
+    from random import Random
+    from nano_vllm_amd import LLM, SamplingParams
+    rnd = Random(0)
+    prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(100, 1024))] for _ in range(40)]
+    outs_len = [rnd.randint(20, 60) for _ in range(40)]
+    sps = [SamplingParams(temperature=0.0, ignore_eos=True, max_tokens=m) for m in outs_len]
+
+    def run(**kw):
+        llm = LLM(ckpt_06b, max_model_len=4096, dummy_weights=True, num_kvcache_blocks=400, **kw)
+        toks = [o["token_ids"] for o in llm.generate(prompts, sps, use_tqdm=False)]
+        llm.exit()
+        return toks
+
+    graph = run(enforce_eager=False)
+    again = run(enforce_eager=False)
+    eager = run(enforce_eager=True)
+    assert [len(t) for t in graph] == outs_len
+    assert graph == again
+    assert graph == eager
+    llm = LLM(ckpt_06b, max_model_len=4096, dummy_weights=True, num_kvcache_blocks=400, enforce_eager=True)
+    solo = llm.generate([prompts[7]], SamplingParams(temperature=0.0, ignore_eos=True, max_tokens=4), use_tqdm=False)
+    llm.exit()
+    assert solo[0]["token_ids"][:1] == graph[7][:1]

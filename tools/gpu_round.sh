@@ -15,10 +15,10 @@ tests)
 bench)
   timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 3000 $OUT/bench.json;;
 prof)
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_replay -o replay -- python $REPO/tools/attn_replay.py > $OUT/replay_under_rocprof.json 2> $OUT/replay_prof.err; echo "prof rc=$?")
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_replay -o replay -- python $REPO/tools/attn_replay.py --fused > $OUT/replay_under_rocprof.json 2> $OUT/replay_prof.err; echo "prof rc=$?")
   f=$(find /tmp/prof_replay -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/replay_kernel_stats.csv && head -5 $OUT/replay_kernel_stats.csv;;
 pmc)
-  (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'decode_' -f csv -d /tmp/pmc_replay -o replay -- python $REPO/tools/attn_replay.py --reps 1 > $OUT/replay_under_pmc.json 2> $OUT/replay_pmc.err; echo "pmc rc=$?")
+  (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'decode_' -f csv -d /tmp/pmc_replay -o replay -- python $REPO/tools/attn_replay.py --fused --reps 1 > $OUT/replay_under_pmc.json 2> $OUT/replay_pmc.err; echo "pmc rc=$?")
   python tools/pmc_summary.py /tmp/pmc_replay $OUT/pmc_fetch_summary.json | tail -30;;
 benchprof)
   (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_bench -o bench -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err; echo "benchprof rc=$?")
@@ -28,7 +28,7 @@ probe)
 gemm)
   timeout 600 python tools/gemm_bench.py > $OUT/gemm_bench.json 2> $OUT/gemm_bench.err; echo "gemm rc=$?"; tail -c 1500 $OUT/gemm_bench.err; cat $OUT/gemm_bench.json;;
 replay)
-  timeout 600 python tools/attn_replay.py > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
+  timeout 600 python tools/attn_replay.py --fused > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
 *) echo "unknown step $w";;
 esac
 done
