@@ -13,6 +13,11 @@
 //     rescale is lane-local). The MFMA k-slot <-> key mapping of the P.V product is permuted
 //     to match the S^T accumulator layout, so P never moves between lanes.
 //   * online softmax in fp32 (base-2), P rounded to bf16 before P.V, fp32 accumulation.
+//   * K/V tiles are double-buffered in LDS and staged through registers with the issue-early /
+//     write-late split (cdna_hip_programming.md T14): the global loads of tile t+1 are issued before
+//     the QK^T of tile t and written to the other LDS buffer after its P.V, so HBM/L2 latency hides
+//     under the MFMA phases and there is ONE workgroup barrier per tile.
+//   * a wave skips the MFMA work of key tiles that lie entirely above its 32 rows' causal frontier.
 // The (sequence, q-block) of a workgroup is found on device from cu_seqlens_q (prefix sum in
 // LDS + binary search), so no host-side tile list is needed.
 #include "common.h"
@@ -34,16 +39,17 @@ struct SeqTile {
   int seq, qblk;
 };
 
+constexpr int kTileBytes = kKBlk * (kKRowB + kVRowB);   // one K + V tile pair in LDS
+
 template <bool PAGED>
-__global__ __launch_bounds__(256) void prefill_attn_kernel(
+__global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_tok_stride,
     int64_t v_tok_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int num_seqs, int hq,
     int hkv, int block_size, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* k_lds = smem;                          // 64 x 256 B
-  unsigned char* v_lds = smem + kKBlk * kKRowB;         // 64 x 320 B
-  int* wsum = reinterpret_cast<int*>(v_lds + kKBlk * kVRowB);
+  // two {K: 64 x 256 B, V: 64 x 320 B} tile buffers, then the tile-lookup scratch
+  int* wsum = reinterpret_cast<int*>(smem + 2 * kTileBytes);
   int* pre = wsum + 4;                                  // [num_seqs + 1]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -78,16 +84,21 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
     }
   }
   __syncthreads();
-  const int tile = blockIdx.x;
-  if (tile >= pre[num_seqs]) return;  // grid is an upper bound
+  // Longest-first dispatch: workgroups are launched in block-id order and a q-block's work grows with its
+  // index (causal), so tiles are taken from the END of the list and the head index varies fastest — the
+  // short tiles fill the tail instead of the 64-tile ones (measured 1.2-1.4x on 4 x 4096 / 1 x 16384).
+  if ((int)blockIdx.y >= pre[num_seqs]) return;  // grid is an upper bound
+  const int tile = pre[num_seqs] - 1 - (int)blockIdx.y;
   int lo = 0, hi_s = num_seqs;
   while (hi_s - lo > 1) {
     const int mid = (lo + hi_s) >> 1;
     if (pre[mid] <= tile) lo = mid; else hi_s = mid;
   }
-  const int seq = lo;
-  const int qblk = tile - pre[seq];
-  const int head = blockIdx.y;
+  // wave-uniform by construction, but read out of LDS: tell the compiler (scalar registers, scalar loads of
+  // cu_seqlens / block tables, SGPR-based K/V addressing whose VGPR offsets stay live across the loop)
+  const int seq = __builtin_amdgcn_readfirstlane(lo);
+  const int qblk = __builtin_amdgcn_readfirstlane(tile - pre[seq]);
+  const int head = blockIdx.x;
   const int kvh = head / (hq / hkv);
 
   const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
@@ -105,6 +116,10 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
 #pragma unroll
     for (int ds = 0; ds < 8; ++ds) qf[ds] = as_bf16x8(*reinterpret_cast<const u32x4_t*>(qp + ds * 16));
   }
+  // Keep the Q loads ahead of the first tile's staging loads: the prologue's wait for that tile then also
+  // retires them. (If hipcc sinks them to the loop head, its waitcnt pass keeps per-fragment vmcnt waits
+  // inside the loop, which drain the in-flight staging loads in the middle of every QK^T phase.)
+  __builtin_amdgcn_sched_barrier(0);
 
   f32x16_t oacc[4];
 #pragma unroll
@@ -114,66 +129,127 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
   float m_run = kNegBig, l_run = 0.f;
 
   const int kmax_vis = qi_c + off;  // last key this query may see
-
-  for (int kt = 0; kt < kv_end; kt += kKBlk) {
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage K and V tiles (64 rows x 256 B each): 1024 16-byte chunks per tensor ----------
-    {
-      int64_t kbase, vbase, kstride, vstride;
-      if constexpr (PAGED) {
-        const int blk = block_tables[(int64_t)seq * bt_stride + kt / block_size];
-        kbase = (((int64_t)blk * hkv + kvh) * block_size + (kt % block_size)) * 128;
-        vbase = kbase;
-        kstride = vstride = 128;
-      } else {
-        kbase = (int64_t)(k0 + kt) * k_tok_stride + kvh * 128;
-        vbase = (int64_t)(k0 + kt) * v_tok_stride + kvh * 128;
-        kstride = k_tok_stride;
-        vstride = v_tok_stride;
-      }
-      const int rows_ok = lk - kt;  // rows >= rows_ok are clamped to the last valid row (masked later)
+  // loop-invariant LDS byte offsets of this lane's K fragments (row qcol, swizzled slot) and V transpose reads
+  int kslot[8];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int chunk = tid + n * 256;
-        const int row = chunk >> 4, c16 = chunk & 15;
-        const int rsrc = row < rows_ok ? row : rows_ok - 1;
-        const u32x4_t kw = *reinterpret_cast<const u32x4_t*>(k + kbase + (int64_t)rsrc * kstride + c16 * 8);
-        const u32x4_t vw = *reinterpret_cast<const u32x4_t*>(v + vbase + (int64_t)rsrc * vstride + c16 * 8);
-        *reinterpret_cast<u32x4_t*>(k_lds + row * kKRowB + ((c16 ^ (row & 15)) << 4)) = kw;
-        *reinterpret_cast<u32x4_t*>(v_lds + row * kVRowB + (c16 << 4)) = vw;
-      }
-    }
-    __syncthreads();
+  for (int ds = 0; ds < 8; ++ds) kslot[ds] = qcol * kKRowB + (((ds * 2 + hi) ^ (qcol & 15)) << 4);
+  const int i16 = lane & 15;
+  const int vlane = (4 * hi + (i16 >> 2)) * kVRowB + (16 * ((lane >> 4) & 1) + (i16 & 3) * 4) * 2;
+  const f32x16_t kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+  // ---- K/V staging: each thread moves 4 16-byte chunks of K and of V per tile ------------------
+  u32x4_t kreg[4], vreg[4];
+  // this thread's chunk n of a tile: row (tid >> 4) + 16 n, 16-byte column tid & 15; element offsets from
+  // the tile's first row are loop-invariant (no 64-bit multiplies in the loop)
+  const int64_t kstride = PAGED ? 128 : k_tok_stride, vstride = PAGED ? 128 : v_tok_stride;
+  const int srow = tid >> 4, sc16 = tid & 15;
+  unsigned int koff[4], voff[4];   // BYTE offsets, unsigned: the loads use the SGPR-base + 32-bit VGPR offset form
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    koff[n] = ((unsigned int)((srow + n * 16) * kstride) + sc16 * 8) * 2u;
+    voff[n] = ((unsigned int)((srow + n * 16) * vstride) + sc16 * 8) * 2u;
+  }
+  // Loads go through buffer descriptors (SGPR base + SGPR tile offset + the loop-invariant VGPR byte
+  // offsets above): no per-tile address VALU, nothing the loads depend on is rewritten while they are in
+  // flight, and rows past the end of the sequence / block come back as zeros from the hardware range check
+  // (they are masked anyway).
+  auto stage_load = [&](int kt) {       // issue the global loads of the tile starting at key kt
+    __amdgpu_buffer_rsrc_t krs, vrs;
+    int ksoff, vsoff;
+    if constexpr (PAGED) {
+      const int blk = block_tables[(int64_t)seq * bt_stride + kt / block_size];
+      const int64_t base = (((int64_t)blk * hkv + kvh) * block_size + (kt % block_size)) * 128;
+      krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + base), 0, kKBlk * 256, 0x00020000);
+      vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + base), 0, kKBlk * 256, 0x00020000);
+      ksoff = vsoff = 0;
+    } else {
+      krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)k0 * k_tok_stride + kvh * 128), 0,
+                                              (int)(lk * kstride * 2), 0x00020000);
+      vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)k0 * v_tok_stride + kvh * 128), 0,
+                                              (int)(lk * vstride * 2), 0x00020000);
+      ksoff = (int)(kt * kstride * 2);
+      vsoff = (int)(kt * vstride * 2);
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      kreg[n] = __builtin_amdgcn_raw_buffer_load_b128(krs, koff[n], ksoff, 0);
+      vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[n], vsoff, 0);
+    }
+  };
+  auto stage_write = [&](int buf) {     // registers -> LDS tile buffer `buf`
+    unsigned char* kl = smem + buf * kTileBytes;
+    unsigned char* vl = kl + kKBlk * kKRowB;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int chunk = tid + n * 256;
+      const int row = chunk >> 4, c16 = chunk & 15;
+      *reinterpret_cast<u32x4_t*>(kl + row * kKRowB + ((c16 ^ (row & 15)) << 4)) = kreg[n];
+      *reinterpret_cast<u32x4_t*>(vl + row * kVRowB + (c16 << 4)) = vreg[n];
+    }
+  };
+  // keys this WAVE's 32 rows can see: tiles starting above wave_kmax carry no work for it
+  const int wave_kmax = min(qblk * kQBlk + wave * 32 + 31, lq - 1) + off;
+  const int wave_kmin = min(qblk * kQBlk + wave * 32, lq - 1) + off;   // ... and all of them see keys <= wave_kmin
+
+  if (kv_end > 0) {
+    stage_load(0);
+    stage_write(0);
+  }
+  __syncthreads();
+
+  int buf = 0;
+  for (int kt = 0; kt < kv_end; kt += kKBlk, buf ^= 1) {
+    const bool more = kt + kKBlk < kv_end;
+    const unsigned char* k_lds = smem + buf * kTileBytes;
+    const unsigned char* v_lds = k_lds + kKBlk * kKRowB;
     // ---- S^T tile: 2 key blocks x 32 keys; lane = query column ---------------------------------
-    f32x16_t sacc[2];
+    f32x16_t sacc[2] = {kZero16, kZero16};
+    if (kt <= wave_kmax) {
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
+      // A operand: lane (key row kb*32 + qcol, hi) holds d = ds*16 + 8*hi .. +8 (swizzled 16-byte slot)
+      const unsigned char* kr = k_lds + kb * 32 * kKRowB;
+      sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[0])), qf[0], kZero16, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[kb][r] = 0.f;
-      const int row = kb * 32 + qcol;  // A operand: lane (key row, hi) holds d = ds*16 + 8*hi .. +8
-#pragma unroll
-      for (int ds = 0; ds < 8; ++ds) {
-        const int slot = (ds * 2 + hi) ^ (row & 15);
-        const bf16x8_t a = as_bf16x8(*reinterpret_cast<const u32x4_t*>(k_lds + row * kKRowB + (slot << 4)));
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ds], sacc[kb], 0, 0, 0);
-      }
+      for (int ds = 1; ds < 8; ++ds)
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[ds])), qf[ds], sacc[kb], 0, 0, 0);
     }
-    // ---- mask + online softmax (base 2) ----------------------------------------------------------
-    float mx = kNegBig;
+    }  // kt <= wave_kmax (QK^T)
+    // next tile's loads: issued after QK^T (hipcc's waitcnt pass otherwise drains them inside it), in
+    // flight under the softmax and the P.V MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stage_load(kt + kKBlk);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt <= wave_kmax) {
+    // ---- online softmax (base 2; the softmax scale is folded into the exponent's FMA) --------------
+    // Only tiles that straddle this wave's causal frontier need the per-element mask.
+    if (kt + kKBlk - 1 > wave_kmin) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          sacc[kb][r] = key <= kmax_vis ? sacc[kb][r] : kNegBig;
+        }
+    }
+    float mx = sacc[0][0];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-        const float s = key <= kmax_vis ? sacc[kb][r] * scale_log2e : kNegBig;
-        sacc[kb][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
+    const float m_new = fmaxf(m_run, mx * scale_log2e);
+    if (__any(m_new > m_run)) {          // some row's running max moved: rescale (exact no-op otherwise)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      m_run = m_new;
+    }
     float psum = 0.f;
     bf16x8_t pf[2][2];  // [kb][r0]: P^T fragment (B operand), k-slot (hi, e) <-> acc reg r0*8 + e
 #pragma unroll
@@ -182,28 +258,22 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
       for (int r0 = 0; r0 < 2; ++r0)
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float p = exp2f(sacc[kb][r0 * 8 + e] - m_new);
+          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r0 * 8 + e], scale_log2e, -m_run));
           psum += p;
           pf[kb][r0][e] = (bf16_t)p;
         }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T . P^T : A operand lane (d = lane&31, hi) needs V[key(hi, e)][d] ----------
     // key(hi, e) = kb*32 + 16*r0 + 4*hi + (e & 3) + 8*(e >> 2): two transpose reads of 4 keys.
-    const int i16 = lane & 15;
+    const unsigned char* vb = v_lds + vlane;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r0 = 0; r0 < 2; ++r0) {
-        const int keybase = kb * 32 + 16 * r0 + 4 * hi;
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-          const int colb = (db * 32 + 16 * ((lane >> 4) & 1) + (i16 & 3) * 4) * 2;
-          const unsigned char* p0 = v_lds + (keybase + (i16 >> 2)) * kVRowB + colb;
+          const unsigned char* p0 = vb + (kb * 32 + 16 * r0) * kVRowB + db * 64;   // compile-time offset
           const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4_t*)(p0));
           const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -213,6 +283,10 @@ __global__ __launch_bounds__(256) void prefill_attn_kernel(
                                                              0, 0, 0);
         }
       }
+    }  // kt <= wave_kmax
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stage_write(buf ^ 1);     // the other buffer was last read one barrier ago
+    __syncthreads();
   }
 
   // ---- epilogue: normalise and store O[query][d] ------------------------------------------------
@@ -260,10 +334,25 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   if (total_q == 0 || num_seqs == 0) return NVL_OK;
   const int64_t tiles = (total_q + kQBlk - 1) / kQBlk + num_seqs;  // upper bound on sum ceil(Lq/128)
   NVL_REQUIRE(tiles < (1ll << 31), "nvl_attn_prefill_varlen: too many query tiles");
-  const size_t lds = (size_t)kKBlk * (kKRowB + kVRowB) + 4 * sizeof(int) + (size_t)(num_seqs + 1) * sizeof(int);
+  const size_t lds = (size_t)2 * kTileBytes + 4 * sizeof(int) + (size_t)(num_seqs + 1) * sizeof(int);
   const float sl2 = softmax_scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid((unsigned)tiles, (unsigned)num_q_heads);
+  NVL_REQUIRE(tiles <= 65535, "nvl_attn_prefill_varlen: too many query tiles (%lld)", (long long)tiles);
+  dim3 grid((unsigned)num_q_heads, (unsigned)tiles);
+  static size_t lds_cap = 0;            // dynamic LDS above 64 KiB must be opted into per kernel
+  if (lds > lds_cap) {
+    const size_t want = lds < 160 * 1024 ? lds + 16 * 1024 : lds;   // headroom: num_seqs moves it by a few KiB
+    const size_t cap = want > 160 * 1024 ? 160 * 1024 : want;
+    NVL_REQUIRE(lds <= 160 * 1024, "nvl_attn_prefill_varlen: %d sequences need %zu B of LDS (> 160 KiB)", num_seqs, lds);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess) {
+      nvl_set_error("nvl_attn_prefill_varlen: cannot reserve %zu B of LDS", cap);
+      return NVL_ELAUNCH;
+    }
+    lds_cap = cap;
+  }
   if (paged) {
     hipLaunchKernelGGL(prefill_attn_kernel<true>, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables,
