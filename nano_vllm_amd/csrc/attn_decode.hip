@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, G == 4 ? 2 : 1) void decode_stream_kernel(   /
   int* wsum = reinterpret_cast<int*>(smem_raw);
   int* pre = wsum + kWaves;  // tile prefix [batch + 1]
 
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane & 15, rq = lane >> 4;
   const int hq = hkv * G;
 
@@ -132,9 +132,11 @@ __global__ __launch_bounds__(256, G == 4 ? 2 : 1) void decode_stream_kernel(   /
       const int mid = (lo + hi) >> 1;
       if ((int64_t)pre[mid] * hkv <= g) lo = mid; else hi = mid;
     }
-    const int b = lo;
-    const int nb = pre[b + 1] - pre[b];                 // tiles per kv-head of this sequence (> 0 here)
-    const int64_t base_b = (int64_t)pre[b] * hkv;
+    // wave-uniform by construction (every lane ran the same search on the same LDS words): say so, so the
+    // segment bookkeeping, block-table loads and tile base addresses live in scalar registers
+    const int b = __builtin_amdgcn_readfirstlane(lo);
+    const int nb = __builtin_amdgcn_readfirstlane(pre[b + 1] - pre[b]);   // tiles per kv-head of this sequence (> 0 here)
+    const int64_t base_b = (int64_t)__builtin_amdgcn_readfirstlane(pre[b]) * hkv;
     const int r = (int)(g - base_b);
     const int h = r / nb;
     const int t0 = r - h * nb;

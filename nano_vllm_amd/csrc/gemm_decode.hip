@@ -314,13 +314,17 @@ int dispatch_kb(const void* x, const void* w, void* out, int64_t m, int n, int k
 }
 
 // s = bf16(sum_s part[s][row]) + residual; residual <- bf16(s); y = bf16(s * rstd * w)
-template <int T>
-__global__ __launch_bounds__(T) void add_rmsnorm_splitk_kernel(const float* __restrict__ part, int splits,
+// One workgroup per row, ONE 8-element chunk per thread round (T = hidden/8 threads when that is <= 256):
+// every load of a thread — S slab pieces, residual, weight — is independent and issued up front, so the
+// kernel is one memory round trip + a block reduction long (it is latency-bound: <= a few MB in flight).
+template <int T, int S>
+__global__ __launch_bounds__(T) void add_rmsnorm_splitk_kernel(const float* __restrict__ part, int splits_rt,
                                                                 int64_t split_stride, bf16_t* __restrict__ residual,
                                                                 const bf16_t* __restrict__ weight,
                                                                 bf16_t* __restrict__ y, int hidden, float eps) {
   constexpr int kMaxChunks = 4;
-  __shared__ float red[T / NVL_WAVE];
+  __shared__ float red[(T + NVL_WAVE - 1) / NVL_WAVE];
+  const int splits = S > 0 ? S : splits_rt;
   const int64_t row = blockIdx.x;
   const float* pr = part + row * hidden;
   bf16_t* rr = residual + row * hidden;
@@ -328,12 +332,33 @@ __global__ __launch_bounds__(T) void add_rmsnorm_splitk_kernel(const float* __re
   const int nchunks = hidden >> 3;
   float v[kMaxChunks][8];
   u32x4_t wraw[kMaxChunks], rraw[kMaxChunks];
+  f32x4_t pa[kMaxChunks], pb[kMaxChunks];
 #pragma unroll
   for (int c = 0; c < kMaxChunks; ++c) {
     const int chunk = threadIdx.x + c * T;
     if (chunk < nchunks) {
       wraw[c] = *reinterpret_cast<const u32x4_t*>(weight + chunk * 8);
       rraw[c] = *reinterpret_cast<const u32x4_t*>(rr + chunk * 8);
+      pa[c] = *reinterpret_cast<const f32x4_t*>(pr + chunk * 8);
+      pb[c] = *reinterpret_cast<const f32x4_t*>(pr + chunk * 8 + 4);
+      if constexpr (S > 0) {
+        f32x4_t ta[S > 1 ? S - 1 : 1], tb[S > 1 ? S - 1 : 1];
+#pragma unroll
+        for (int sidx = 1; sidx < S; ++sidx) {
+          ta[sidx - 1] = *reinterpret_cast<const f32x4_t*>(pr + sidx * split_stride + chunk * 8);
+          tb[sidx - 1] = *reinterpret_cast<const f32x4_t*>(pr + sidx * split_stride + chunk * 8 + 4);
+        }
+#pragma unroll
+        for (int sidx = 1; sidx < S; ++sidx) {   // same summation order as the runtime-S loop: s = 0, 1, 2, ...
+          pa[c] += ta[sidx - 1];
+          pb[c] += tb[sidx - 1];
+        }
+      } else {
+        for (int sidx = 1; sidx < splits; ++sidx) {
+          pa[c] += *reinterpret_cast<const f32x4_t*>(pr + sidx * split_stride + chunk * 8);
+          pb[c] += *reinterpret_cast<const f32x4_t*>(pr + sidx * split_stride + chunk * 8 + 4);
+        }
+      }
     }
   }
   float ss = 0.f;
@@ -341,18 +366,12 @@ __global__ __launch_bounds__(T) void add_rmsnorm_splitk_kernel(const float* __re
   for (int c = 0; c < kMaxChunks; ++c) {
     const int chunk = threadIdx.x + c * T;
     if (chunk < nchunks) {
-      f32x4_t a = *reinterpret_cast<const f32x4_t*>(pr + chunk * 8);
-      f32x4_t b = *reinterpret_cast<const f32x4_t*>(pr + chunk * 8 + 4);
-      for (int sidx = 1; sidx < splits; ++sidx) {
-        a += *reinterpret_cast<const f32x4_t*>(pr + sidx * split_stride + chunk * 8);
-        b += *reinterpret_cast<const f32x4_t*>(pr + sidx * split_stride + chunk * 8 + 4);
-      }
       float r[8];
       unpack8(rraw[c], r);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        v[c][i] = round_bf16(a[i]) + r[i];
-        v[c][i + 4] = round_bf16(b[i]) + r[i + 4];
+        v[c][i] = round_bf16(pa[c][i]) + r[i];
+        v[c][i + 4] = round_bf16(pb[c][i]) + r[i + 4];
       }
       *reinterpret_cast<u32x4_t*>(rr + chunk * 8) = pack8(v[c]);
 #pragma unroll
@@ -381,6 +400,22 @@ __global__ __launch_bounds__(T) void add_rmsnorm_splitk_kernel(const float* __re
       *reinterpret_cast<u32x4_t*>(yr + chunk * 8) = pack8(o);
     }
   }
+}
+
+template <int T>
+void launch_add_rmsnorm_splitk(const float* partials, int splits, int64_t split_stride, bf16_t* residual,
+                               const bf16_t* weight, bf16_t* y, int64_t rows, int hidden, float eps, hipStream_t s) {
+#define NVL_SPLITK_CASE(SS)                                                                                       \
+  hipLaunchKernelGGL((add_rmsnorm_splitk_kernel<T, SS>), dim3((unsigned)rows), dim3(T), 0, s, partials, splits, \
+                     split_stride, residual, weight, y, hidden, eps)
+  switch (splits) {
+    case 1: NVL_SPLITK_CASE(1); break;
+    case 2: NVL_SPLITK_CASE(2); break;
+    case 4: NVL_SPLITK_CASE(4); break;
+    case 8: NVL_SPLITK_CASE(8); break;
+    default: NVL_SPLITK_CASE(0); break;
+  }
+#undef NVL_SPLITK_CASE
 }
 
 }  // namespace
@@ -424,12 +459,15 @@ extern "C" int nvl_add_rmsnorm_splitk(const float* partials, int splits, void* r
   if (rows == 0) return NVL_OK;
   hipStream_t s = (hipStream_t)stream;
   const int64_t split_stride = rows * (int64_t)hidden;
-  if (hidden <= 64 * 8 * 4) {
-    hipLaunchKernelGGL((add_rmsnorm_splitk_kernel<64>), dim3((unsigned)rows), dim3(64), 0, s, partials, splits,
-                       split_stride, (bf16_t*)residual, (const bf16_t*)weight, (bf16_t*)y, hidden, eps);
+  bf16_t* rp = (bf16_t*)residual;
+  const bf16_t* wp = (const bf16_t*)weight;
+  bf16_t* yp = (bf16_t*)y;
+  if (hidden <= 64 * 8) {
+    launch_add_rmsnorm_splitk<64>(partials, splits, split_stride, rp, wp, yp, rows, hidden, eps, s);
+  } else if (hidden <= 128 * 8) {
+    launch_add_rmsnorm_splitk<128>(partials, splits, split_stride, rp, wp, yp, rows, hidden, eps, s);
   } else {
-    hipLaunchKernelGGL((add_rmsnorm_splitk_kernel<256>), dim3((unsigned)rows), dim3(256), 0, s, partials, splits,
-                       split_stride, (bf16_t*)residual, (const bf16_t*)weight, (bf16_t*)y, hidden, eps);
+    launch_add_rmsnorm_splitk<256>(partials, splits, split_stride, rp, wp, yp, rows, hidden, eps, s);
   }
   return nvl_check_launch("nvl_add_rmsnorm_splitk");
 }
