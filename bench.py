@@ -66,7 +66,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # Functional check of the N>1 path on a 1-GPU box (not a measurement): NVL_BENCH_SHARE_GPU=1 puts every
+    # rank on GPU 0 and NVL_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+    share_gpu = os.environ.get("NVL_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("NVL_BENCH_BACKEND", "nccl")
+    if world > 1 and not share_gpu:
         # one replica per GPU: each process sees only its own device
         os.environ["HIP_VISIBLE_DEVICES"] = str(local_rank)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -78,8 +82,11 @@ def main():
     if rank == 0 or world == 1:
         nvl_build.build()
     if world > 1:
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank,
-                                device_id=torch.device("cuda", 0))
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank,
+                                    device_id=torch.device("cuda", 0))
+        else:
+            dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
         dist.barrier()
 
     from nano_vllm_amd.weights import write_synthetic_checkpoint
@@ -147,7 +154,7 @@ def main():
     elapsed = time.perf_counter() - t0
     rec["on"] = False
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

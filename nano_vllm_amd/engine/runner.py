@@ -86,6 +86,8 @@ class ModelRunner:
 
         if self.world_size > 1:
             dist.init_process_group("nccl", f"tcp://127.0.0.1:{_DIST_PORT}", world_size=self.world_size, rank=rank)
+        from .. import tp
+        tp.init(rank if self.world_size > 1 else 0, self.world_size)
         torch.cuda.set_device(rank)
         self.device = torch.device("cuda", rank)
         self.geo = model_geometry(hf, self.world_size)
@@ -142,6 +144,8 @@ class ModelRunner:
         torch.cuda.synchronize()
         if self.world_size > 1:
             dist.destroy_process_group()
+            from .. import tp
+            tp.init(0, 1)
 
     def loop(self):
         while True:

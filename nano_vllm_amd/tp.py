@@ -19,15 +19,29 @@ _OVERLAP_CHUNKS = 4
 _side_stream: torch.cuda.Stream | None = None
 
 
+# The tensor-parallel group is EXPLICIT state set by the engine (`init`), never inferred from
+# torch.distributed's default group: a caller may have its own process group for something else —
+# bench.py --gpus N runs N independent TP=1 replicas under one data-parallel group, and those engines
+# must not shard their weights across it.
+_rank, _size = 0, 1
+
+
+def init(rank: int, size: int) -> None:
+    """Declare this process' place in the engine's tensor-parallel group (size 1 = no TP). With
+    size > 1 the default torch.distributed group must be that group (engine/runner.py creates it)."""
+    global _rank, _size
+    assert 0 <= rank < size
+    assert size == 1 or (dist.is_initialized() and dist.get_world_size() == size), "TP group not initialised"
+    _rank, _size = rank, size
+
+
 def world() -> tuple[int, int]:
-    """(rank, world_size); (0, 1) when no process group exists (single-GPU fast path)."""
-    if dist.is_available() and dist.is_initialized():
-        return dist.get_rank(), dist.get_world_size()
-    return 0, 1
+    """(rank, world_size) of the engine's tensor-parallel group; (0, 1) without TP."""
+    return _rank, _size
 
 
 def all_reduce(t: torch.Tensor) -> torch.Tensor:
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _size > 1:
         dist.all_reduce(t)
     return t
 

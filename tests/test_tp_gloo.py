@@ -29,6 +29,8 @@ def _free_port():
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     dist.init_process_group("gloo", f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
+    from nano_vllm_amd import tp
+    tp.init(rank, world)
     try:
         import torch.nn.functional as F
         from nano_vllm_amd import layers as L
