@@ -31,7 +31,8 @@ QWEN3_SHAPES = {
     "qwen3-32b": (5120, 25600, 64, 64, 8, False),
     # tiny shapes for tests (same architecture, head_dim 128)
     "qwen3-tiny": (256, 512, 2, 4, 2, True),
-    "qwen3-tiny-untied": (256, 512, 3, 8, 2, False),
+    "qwen3-tiny-untied": (256, 512, 3, 8, 2, False),     # G = 4, separate lm_head (8B-like)
+    "qwen3-tiny-g8": (512, 768, 2, 8, 1, False),          # G = 8, one kv head (32B / TP=8 per-rank shape)
 }
 
 

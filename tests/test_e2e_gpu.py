@@ -100,6 +100,23 @@ def test_tiny_model_greedy_parity(tiny_ckpt, eager):
     assert worst <= TOL and exact >= 0.9 * total
 
 
+@pytest.mark.parametrize("name", ["qwen3-tiny-untied", "qwen3-tiny-g8"])
+def test_other_head_geometries_greedy_parity(name):
+    """GQA group sizes 4 (Qwen3-8B-like, untied lm_head) and 8 with a single kv head (Qwen3-32B at TP=8):
+    the G=4 / G=8 instantiations of the fused decode kernel and of the MFMA prefill kernel, end to end."""
+    from nano_vllm_amd.weights import write_synthetic_checkpoint
+    path = tempfile.mkdtemp(prefix=name.replace("-", "_") + "_")
+    write_synthetic_checkpoint(path, name, seed=1, vocab_size=512, max_position_embeddings=2048)
+    prompts = _prompts(5, 5, 700, 512, seed=9)
+    max_tokens = [12, 30, 5, 21, 9]
+    outs, rec, nblk = _run_ours(path, prompts, max_tokens, enforce_eager=False, max_model_len=2048,
+                                num_kvcache_blocks=24, max_num_seqs=8)
+    assert [len(o["token_ids"]) for o in outs] == max_tokens
+    exact, total, worst = _judge(path, prompts, max_tokens, rec, nblk, max_num_seqs=8)
+    print(f"{name}: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
+    assert worst <= TOL and exact >= 0.9 * total
+
+
 def test_tiny_model_chunked_prefill_and_preemption(tiny_ckpt):
     """Small token budget + small block pool: chunked prefill (paged-prefix attention path),
     prefix-cache reuse of a shared 512-token prefix, and preemption by recompute."""
