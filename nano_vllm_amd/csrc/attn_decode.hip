@@ -300,6 +300,244 @@ __global__ __launch_bounds__(256, G == 4 ? 2 : 1) void decode_stream_kernel(   /
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// G = 8 (Qwen3-32B per-rank shapes at TP 4 / 8: one K/V row serves 8 query heads, 8 FLOP/B): the packed
+// v_dot2 path above is VALU-bound there (2.4 TB/s), so the scores and the P.V product go to the matrix
+// cores. Same stream-K bookkeeping, same split-partial format, same HBM->VGPR non-temporal tile loads;
+// a wave then lays its 16 KiB tile out in a PRIVATE LDS region (no workgroup barriers) and reads it back
+// as v_mfma_f32_16x16x32_bf16 operands:
+//   S^T[16 tokens x 16 heads] = K[16 x 128] . Q^T[128 x 16]      A = K rows (ds_read_b128, XOR-swizzled
+//                                                                 16-byte slots), B = Q^T (registers,
+//                                                                 heads 8..15 are zero padding)
+//   O^T[16 dims  x 16 heads] += V^T[16 x 32] . P^T[32 x 16]      A = V^T via ds_read_b64_tr_b16 (hardware
+//                                                                 transpose of the row-major V tile),
+//                                                                 B = P^T straight from the S^T
+//                                                                 accumulators: the MFMA k-slot <-> token
+//                                                                 map is chosen so P never changes lane
+// Lane (head = lane & 15, quad = lane >> 4) owns one head column: the online softmax is lane-local plus
+// two shuffles, the O rescale is a per-lane scalar. LDS traffic is 2 x 16 KiB per tile per wave, far
+// below what the CU sustains at HBM-bound rates (~10 B/clk/CU).
+constexpr int kMKRow = 256;             // K tile row bytes in LDS (32 rows, swizzled slots)
+constexpr int kMVRow = 288;             // V tile row bytes (256 + 32: conflict-free transpose reads)
+constexpr int kMWaveLds = kTile * (kMKRow + kMVRow);   // 17,408 B per wave
+
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+template <bool FUSED>
+__global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
+    const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
+    int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
+    int* __restrict__ meta, bf16_t* __restrict__ out, int batch, int hkv, int block_size, int slots,
+    float scale_log2e, FusedArgs fa) {
+  constexpr int G = 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* wsum = reinterpret_cast<int*>(smem_raw + kWaves * kMWaveLds);
+  int* pre = wsum + kWaves;  // tile prefix [batch + 1]
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane & 15, rq = lane >> 4;      // load / prologue view: 16 lanes x 8 dims = one row
+  const int head = lane & 15, quad = lane >> 4;   // MFMA view: one head column per lane
+  const int hq = hkv * G;
+  unsigned char* k_lds = smem_raw + wave * kMWaveLds;
+  unsigned char* v_lds = k_lds + kTile * kMKRow;
+
+  chunk_prefix(ctx, batch, kTile, pre, wsum);
+  __syncthreads();
+  const int64_t total = (int64_t)pre[batch] * hkv;
+  const int64_t nwaves = (int64_t)gridDim.x * kWaves;
+  int64_t per = (total + nwaves - 1) / nwaves;
+  if (per < kMinTilesPerWave) per = kMinTilesPerWave;
+  const int64_t wid = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t g1 = min(total, (wid + 1) * per);
+
+  // loop-invariant LDS byte offsets
+  int kfrag[4];   // K A-fragment of dim chunk c: row `head` (= token within the 16-token half), swizzled slot
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kfrag[c] = head * kMKRow + (((4 * c + quad) ^ head) << 4);
+  const int vfrag = (4 * quad + (head >> 2)) * kMVRow + (head & 3) * 8;   // + 32 * db, + 16 rows for the 2nd half
+
+  for (int64_t g = wid * per; g < g1;) {
+    int lo = 0, hi = batch;  // largest b with hkv * pre[b] <= g
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)pre[mid] * hkv <= g) lo = mid; else hi = mid;
+    }
+    const int b = __builtin_amdgcn_readfirstlane(lo);
+    const int nb = __builtin_amdgcn_readfirstlane(pre[b + 1] - pre[b]);
+    const int64_t base_b = (int64_t)__builtin_amdgcn_readfirstlane(pre[b]) * hkv;
+    const int r = (int)(g - base_b);
+    const int h = r / nb;
+    const int t0 = r - h * nb;
+    const int run = (int)min((int64_t)(nb - t0), g1 - g);
+    const int len = ctx[b];
+    const bool owns_last = FUSED && (t0 + run == nb);
+
+    // ---- segment prologue: q (FUSED: norm + rope; new token's k, v) in the 16-lane-row layout, two heads
+    //      groups per pass (rq + 4 it), staged through this wave's K region into the MFMA B layout -------
+    float m_run = kNegBig, l_run = 0.f;
+    f32x4_t oacc[8];
+#pragma unroll
+    for (int db = 0; db < 8; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    {
+      RopeRegs rr = {};
+      u32x4_t wq = {0u, 0u, 0u, 0u}, wk = {0u, 0u, 0u, 0u};
+      const bf16_t* row = FUSED ? q + (int64_t)b * fa.qkv_tok_stride : q + (int64_t)b * hq * 128;
+      if constexpr (FUSED) {
+        int64_t pos = len - 1;
+        pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
+        rr = load_rope_regs(fa.cos_sin + pos * 128, sub);
+        if (fa.q_norm_w != nullptr) {
+          wq = *reinterpret_cast<const u32x4_t*>(fa.q_norm_w + sub * 8);
+          wk = *reinterpret_cast<const u32x4_t*>(fa.k_norm_w + sub * 8);
+        }
+      }
+      u32x4_t qh[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        qh[it] = *reinterpret_cast<const u32x4_t*>(row + (h * G + rq + 4 * it) * 128 + sub * 8);
+        if constexpr (FUSED) qh[it] = norm_rope_head_regs(qh[it], fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
+        *reinterpret_cast<u32x4_t*>(k_lds + (rq + 4 * it) * 256 + sub * 16) = qh[it];   // q tile [8 heads][128]
+      }
+      if constexpr (FUSED) {
+        if (owns_last) {
+          u32x4_t knew = *reinterpret_cast<const u32x4_t*>(row + (hq + h) * 128 + sub * 8);
+          const u32x4_t vnew = *reinterpret_cast<const u32x4_t*>(row + (hq + hkv + h) * 128 + sub * 8);
+          knew = norm_rope_head_regs(knew, fa.k_norm_w != nullptr, wk, fa.eps, rr, sub);
+          const int tl = len - 1;
+          if (rq == 0) {                                           // one 256-byte row each, for later steps
+            const int blk = block_tables[(int64_t)b * bt_stride + tl / block_size];
+            const int64_t dst = (((int64_t)blk * hkv + h) * block_size + (tl % block_size)) * 128 + sub * 8;
+            *reinterpret_cast<u32x4_t*>(kc + dst) = knew;
+            *reinterpret_cast<u32x4_t*>(vc + dst) = vnew;
+            *reinterpret_cast<u32x4_t*>(v_lds + sub * 16) = vnew;                      // v row for the O init
+          }
+          // scores of the new token against the 8 heads, via the same staging region
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {
+            const float sn = row16_allreduce_sum(dot8(knew, qh[it]));
+            if (sub == 0) *reinterpret_cast<float*>(v_lds + 256 + (rq + 4 * it) * 4) = sn;
+          }
+        }
+      }
+    }
+    // (same wave wrote and reads: LDS operations of one wave execute in order)
+    bf16x8_t qb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      u32x4_t w = {0u, 0u, 0u, 0u};
+      if (head < G) w = *reinterpret_cast<const u32x4_t*>(k_lds + head * 256 + (4 * c + quad) * 16);
+      qb[c] = __builtin_bit_cast(bf16x8_t, w);
+    }
+    if constexpr (FUSED) {
+      if (owns_last) {
+        // The new token enters the online softmax as the first key of this wave's segment (m = its score,
+        // l = 1 counted once per head, O = v): its cache row is never read back inside this launch.
+        m_run = *reinterpret_cast<const float*>(v_lds + 256 + (head & 7) * 4) * scale_log2e;
+        l_run = quad == 0 ? 1.f : 0.f;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+          const u32x2_t w = *reinterpret_cast<const u32x2_t*>(v_lds + (16 * db + 4 * quad) * 2);
+          oacc[db] = f32x4_t{bf16lo_to_f32(w[0]), bf16hi_to_f32(w[0]), bf16lo_to_f32(w[1]), bf16hi_to_f32(w[1])};
+        }
+      }
+    }
+    const int len_cached = FUSED ? len - 1 : len;
+
+    for (int ti = t0; ti < t0 + run; ++ti) {
+      const int t = ti * kTile;
+      const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
+      const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
+      const bf16_t* kp = kc + base;
+      const bf16_t* vp = vc + base;
+      u32x4_t kd[kLoads], vd[kLoads];
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) kd[i] = load16_nt(kp + i * 4 * 128);
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) vd[i] = load16_nt(vp + i * 4 * 128);
+      __builtin_amdgcn_sched_barrier(0);  // all 16 loads in flight before the first use
+      // registers -> this wave's LDS tile: row i*4 + rq; K in swizzled 16-byte slots, V row-major (padded)
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) {
+        const int rowi = i * 4 + rq;
+        *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((sub ^ (rowi & 15)) << 4)) = kd[i];
+      }
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
+
+      // ---- S^T: two 16-token halves x four 32-dim chunks ------------------------------------------------
+      f32x4_t sacc[2];
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        sacc[hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const u32x4_t a = *reinterpret_cast<const u32x4_t*>(k_lds + hf * 16 * kMKRow + kfrag[c]);
+          sacc[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qb[c], sacc[hf], 0, 0, 0);
+        }
+      }
+      // ---- online softmax for this lane's head; token of (hf, r) = t + 16 hf + 4 quad + r ------------------
+      float mx = kNegBig;
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const bool valid = (t + 16 * hf + 4 * quad + rr) < len_cached;
+          const float sv = valid ? sacc[hf][rr] * scale_log2e : kNegBig;
+          sacc[hf][rr] = sv;
+          mx = fmaxf(mx, sv);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(m_run, mx);
+      const float alpha = exp2f(m_run - mn);
+      m_run = mn;
+      float psum = 0.f;
+      bf16x8_t pb;     // P^T B operand: k-slot j <-> token 4 quad + j (j < 4), 16 + 4 quad + j - 4 (j >= 4)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          const float pv = exp2f(sacc[hf][rr] - mn);
+          psum += pv;
+          pb[hf * 4 + rr] = (bf16_t)pv;
+        }
+      l_run = l_run * alpha + psum;
+#pragma unroll
+      for (int db = 0; db < 8; ++db) oacc[db] *= alpha;
+      // ---- O^T += V^T . P^T: 8 blocks of 16 dims; A = two transpose reads of 4 tokens x 16 dims --------------
+#pragma unroll
+      for (int db = 0; db < 8; ++db) {
+        const unsigned char* p0 = v_lds + vfrag + db * 32;
+        const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
+        const s16x4_t a1 =
+            __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * kMVRow));
+        const s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), pb, oacc[db], 0, 0, 0);
+      }
+    }
+
+    // ---- emit: lane (head, quad) holds O[head][16 db + 4 quad + r]; l is a per-quad partial -------------------
+    const int64_t seg0 = base_b + (int64_t)h * nb;
+    const int first = (int)(seg0 / per);
+    const int k = (int)(wid - first);
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (head < G) {
+      const int64_t pidx = ((int64_t)b * hq + h * G + head) * slots + k;
+      float* dst = part_o + pidx * 128 + 4 * quad;
+#pragma unroll
+      for (int db = 0; db < 8; ++db) *reinterpret_cast<f32x4_t*>(dst + 16 * db) = oacc[db];
+      if (quad == 0) {
+        part_ml[pidx * 2] = m_run;
+        part_ml[pidx * 2 + 1] = l_run;
+      }
+    }
+    if (lane == 0) meta[b * hkv + h] = (int)((seg0 + nb - 1) / per) - first + 1;   // #partials of (b, h)
+    g += run;
+  }
+}
+
 __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float* __restrict__ part_o,
                                                                      const float* __restrict__ part_ml,
                                                                      const int* __restrict__ meta,
@@ -335,6 +573,42 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
 }
 
 inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 2; }
+
+template <bool FUSED>
+int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
+                        void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
+                        void* workspace, hipStream_t s, const FusedArgs& fa) {
+  constexpr int G = 8;
+  const int hq = hkv * G;
+  const int slots = stream_slots(max_context);
+  float* part_o = (float*)workspace;
+  float* part_ml = part_o + (size_t)batch * hq * slots * 128;
+  int* meta = (int*)(part_ml + (size_t)batch * hq * slots * 2);
+  const size_t lds = (size_t)kWaves * kMWaveLds + kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_kernel<FUSED>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the G = 8 kernel");
+      return NVL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  NVL_REQUIRE(lds <= 160 * 1024, "nvl_paged_attn_decode: batch=%lld needs %zu B of LDS (> 160 KiB)", (long long)batch, lds);
+  static int cus = 0;
+  if (cus == 0) cus = nvl_device_cu_count();
+  int64_t grid = (int64_t)cus * (2 * lds <= 160 * 1024 ? 2 : 1);
+  const int64_t max_tiles = batch * hkv * ((max_context + kTile - 1) / kTile);
+  const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
+  if (grid > max_wg) grid = max_wg;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((decode_mfma8_kernel<FUSED>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
+                     (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
+                     block_size, slots, scale * 1.4426950408889634f, fa);
+  hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
+                     meta, ctx, (bf16_t*)out, hq, hkv, slots);
+  return nvl_check_launch("nvl_paged_attn_decode");
+}
 
 template <int G, bool FUSED>
 int launch_decode_stream(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride,
@@ -378,6 +652,15 @@ extern "C" size_t nvl_paged_attn_decode_workspace_bytes(int64_t max_batch, int n
 
 namespace {
 
+bool use_valu_g8() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("NVL_DECODE_G8_VALU");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v == 1;
+}
+
 int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* block_tables, int64_t bt_stride,
                   const int32_t* context_lens, void* out, int64_t batch, int num_q_heads, int num_kv_heads,
                   int block_size, int64_t num_blocks, int64_t max_context, float softmax_scale, void* workspace,
@@ -408,7 +691,16 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
     NVL_DECODE_CASE(1)
     NVL_DECODE_CASE(2)
     NVL_DECODE_CASE(4)
-    NVL_DECODE_CASE(8)
+    case 8:   // matrix-core variant (the packed-dot kernel is VALU-bound at 8 FLOP/B); NVL_DECODE_G8_VALU=1 keeps it
+      if (!use_valu_g8())
+        return fa ? launch_decode_mfma8<true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
+                                              num_kv_heads, block_size, max_context, softmax_scale, workspace, s, *fa)
+                  : launch_decode_mfma8<false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
+                                               num_kv_heads, block_size, max_context, softmax_scale, workspace, s, none);
+      return fa ? launch_decode_stream<8, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
+                                                num_kv_heads, block_size, max_context, softmax_scale, workspace, s, *fa)
+                : launch_decode_stream<8, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
+                                                 num_kv_heads, block_size, max_context, softmax_scale, workspace, s, none);
     default:
       nvl_set_error("%s: unsupported group size Hq/Hkv=%d (supported 1,2,4,8)", who, G);
       return NVL_EUNSUPPORTED;

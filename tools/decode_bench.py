@@ -70,4 +70,5 @@ res["b16"] = case(16, 100, 2048, 16, 8)
 res["b256_g4"] = case(256, 100, 2048, 32, 8)
 res["b256_g8"] = case(256, 100, 2048, 8, 1)
 res["b256_g1"] = case(256, 100, 2048, 8, 8)
+res["b256_g8_tp4_long"] = case(256, 1024, 4096, 16, 2)     # Qwen3-32B TP=4 per-rank heads, long contexts
 print(json.dumps(res))
