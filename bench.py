@@ -159,7 +159,8 @@ def main():
         elapsed = float(t.item())
 
     result = {
-        "metric": "output tokens/s (bench.py, 256 seqs) Qwen3-0.6B TP=1",
+        "metric": "output tokens/s (bench.py, 256 seqs) Qwen3-0.6B TP=1" if args.model == "qwen3-0.6b" else
+                  f"output tokens/s (bench.py, {args.num_seqs} seqs) {args.model} TP=1",
         "value": total_out * args.steps * world / elapsed,
         "unit": "tok/s",
         "n_gpus": world,

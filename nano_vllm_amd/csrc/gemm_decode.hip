@@ -256,6 +256,10 @@ bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
   for (int c : {4, 3, 2, 1})
     if (kw % c == 0) { kb = c; break; }
   if (!kb) return false;
+  // One pass over K per wave only (K <= 1024 per workgroup K-slice): with more passes the weight fragments of
+  // pass k+1 are not yet prefetched behind pass k and the library GEMM wins (measured on Qwen3-8B shapes:
+  // 42-86 us vs 40-56 us) — the caller keeps hipBLASLt there.
+  if (kw / kb > 1) return false;
   p->kb = kb;
   p->ko = kw / kb;
   p->split = split;

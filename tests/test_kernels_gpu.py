@@ -80,7 +80,7 @@ def test_silu_mul(ops, rows, inter):
 # ------------------------------------------------------------------------------------------
 # skinny decode linears (nvl_linear_decode): oracle = fp32 GEMM rounded where the reference's bf16
 # F.linear rounds (layers/linear.py:54-156), then the reference's SiluAndMul / add-RMSNorm on top.
-LINEAR_SHAPES = [(4096, 1024), (1024, 2048), (6144, 1024), (1024, 3072), (512, 256), (2048, 4096)]
+LINEAR_SHAPES = [(4096, 1024), (6144, 1024), (512, 256), (2048, 768), (1280, 512)]     # one K pass per wave: K <= 1024
 
 
 def _close_to_rounded(y, acc, atol=2e-5):
@@ -108,7 +108,7 @@ def test_linear_decode_bf16(ops, m, n, k):
 
 
 @pytest.mark.parametrize("m", [1, 16, 131, 144, 256, 300])
-@pytest.mark.parametrize("n,k", [(6144, 1024), (512, 256), (24576, 4096)])
+@pytest.mark.parametrize("n,k", [(6144, 1024), (512, 256), (1536, 768)])
 def test_linear_decode_silu(ops, m, n, k):
     """gate|up projection with SiluAndMul as the epilogue (models/qwen3.py:90-113, activation.py:8-11)."""
     x, w, acc = _lin_inputs(m, n, k, 22)
@@ -122,7 +122,7 @@ def test_linear_decode_silu(ops, m, n, k):
 
 
 @pytest.mark.parametrize("m", [1, 16, 131, 144, 256, 300])
-@pytest.mark.parametrize("n,k", [(1024, 2048), (1024, 3072), (4096, 12288), (512, 256)])
+@pytest.mark.parametrize("n,k", [(1024, 2048), (1024, 3072), (256, 512), (512, 256)])
 def test_linear_decode_partials_into_add_rmsnorm(ops, m, n, k):
     """o_proj / down_proj as fp32 split-K partials + the fused slab-sum/add/RMSNorm consumer."""
     x, w, acc = _lin_inputs(m, n, k, 24)
@@ -145,6 +145,7 @@ def test_linear_decode_partials_into_add_rmsnorm(ops, m, n, k):
 def test_linear_decode_unsupported_shapes_are_reported(ops):
     assert ops.linear_decode_splits(16, 4096, 1000, ops.LINEAR_BF16) == 0      # K not a multiple of 256
     assert ops.linear_decode_splits(16, 4096, 128, ops.LINEAR_BF16) == 0       # K < 256
+    assert ops.linear_decode_splits(16, 6144, 4096, ops.LINEAR_BF16) == 0      # > 1 K pass per wave: library GEMM
     assert ops.linear_decode_splits(16, 4100, 1024, ops.LINEAR_BF16) == 0      # N not a multiple of 16
     x = torch.zeros(16, 1000, dtype=BF16, device="cuda")
     w = torch.zeros(4096, 1000, dtype=BF16, device="cuda")

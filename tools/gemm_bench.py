@@ -51,18 +51,25 @@ def check(m, n, k, mode):
     return err / want.abs().max().item()
 
 
-shapes = [("qkv", 4096, 1024, 0), ("o", 1024, 2048, 2), ("gate_up", 6144, 1024, 1), ("down", 1024, 3072, 2)]
+MODELS = {
+    "0.6b": [("qkv", 4096, 1024, 0), ("o", 1024, 2048, 2), ("gate_up", 6144, 1024, 1), ("down", 1024, 3072, 2)],
+    "8b": [("qkv", 6144, 4096, 0), ("o", 4096, 4096, 2), ("gate_up", 24576, 4096, 1), ("down", 4096, 12288, 2)],
+    "32b": [("qkv", 10240, 5120, 0), ("o", 5120, 8192, 2), ("gate_up", 51200, 5120, 1), ("down", 5120, 25600, 2)],
+}
+model = sys.argv[1] if len(sys.argv) > 1 else "0.6b"
+shapes = MODELS[model]
+res["model"] = model
 res["relerr"] = {}
 for name, n, k, mode in shapes:
-    for m in (1, 16, 131, 144, 256, 300, 512):
+    for m in ((1, 16, 131, 144, 256, 300, 512) if model == "0.6b" else (16, 144, 256)):
         res["relerr"][f"{name}_m{m}"] = check(m, n, k, mode)
 res["relerr_max"] = max(res["relerr"].values())
 
 res["time_us"] = {}
-for m in (16, 32, 64, 96, 144, 208, 256, 512):
+for m in ((16, 32, 64, 96, 144, 208, 256, 512) if model == "0.6b" else (16, 64, 144, 256)):
     for name, n, k, mode in shapes:
         # rotate over several weight copies so the weights come from HBM like in the real step
-        ws = [(torch.randn(n, k, device="cuda") * 0.05).to(BF16) for _ in range(24)]
+        ws = [(torch.randn(n, k, device="cuda") * 0.05).to(BF16) for _ in range(24 if model == "0.6b" else 6)]
         x = torch.randn(m, k, device="cuda").to(BF16)
         outs = ops.linear_decode(x, ws[0], mode)
         def ours():
