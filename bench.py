@@ -171,7 +171,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "bf16",
-        "data": "synthetic (seeded random weights, Qwen3-0.6B shapes; token ids randint(0,10000) as reference bench.py)",
+        "data": f"synthetic (seeded random weights, {args.model} shapes; token ids randint(0,10000) as reference bench.py)",
         "config": {"workload": f"nano-vllm bench.py: {args.num_seqs} seqs, in/out U[100,1024], T=0.6, ignore_eos, "
                                f"max_model_len 4096, {args.model}", "parallelism": f"dp{world} (1 engine replica per GPU, TP=1)",
                    "hipgraph": not args.eager, "kv_blocks": llm.config.num_kvcache_blocks,
@@ -209,7 +209,8 @@ def roofline_replay(torch, runner, rec) -> dict:
     step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * 2 * L
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"]),
-            "kernel": f"decode_stream_kernel<{hq // hkv}, fused> + decode_stream_combine_kernel (nvl_paged_attn_decode_fused: the launch the decode step makes)",
+            "kernel": (f"decode_stream_kernel<{hq // hkv}, fused>" if hq // hkv != 8 else "decode_mfma8_kernel<fused>")
+                      + " + decode_stream_combine_kernel (nvl_paged_attn_decode_fused: the launch the decode step makes)",
             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],
             "launches_timed": r["launches_timed"], "decode_steps_in_pass": rec["steps"],
             "kv_bytes_read_in_pass": step_bytes, "frac_of_measured_achievable_6.29TBps": achieved / 6290.0}
