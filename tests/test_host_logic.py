@@ -187,3 +187,73 @@ def test_sequence_pickle_is_slim():
     assert small < 200 < big
     t = pickle.loads(pickle.dumps(s))
     assert t.last_token == 999 and t.block_table == [3, 4, 5, 6] and t.num_tokens == 1000 and t.seq_id == s.seq_id
+
+
+# ---- BASELINE.json workloads at FULL size, host side only (schedule shape is token-independent here) --------
+def _drive(cfg_kw, prompts, max_tokens):
+    """Run our scheduler over a workload with a fake token source; returns per-step records."""
+    from types import SimpleNamespace
+    from nano_vllm_amd.api import SamplingParams
+    from nano_vllm_amd.engine.sched import Scheduler
+    from nano_vllm_amd.engine.seq import Sequence
+    cfg = SimpleNamespace(max_num_seqs=512, max_num_batched_tokens=16384, eos=-1, kvcache_block_size=256,
+                          num_kvcache_blocks=8000)
+    cfg.__dict__.update(cfg_kw)
+    Sequence.block_size = 256
+    sched = Scheduler(cfg)
+    for p, m in zip(prompts, max_tokens):
+        sched.add(Sequence(p, SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=m)))
+    steps = []
+    while not sched.is_finished():
+        batch, is_prefill = sched.schedule()
+        steps.append(dict(prefill=is_prefill, n=len(batch), sched=sum(s.num_scheduled_tokens for s in batch),
+                          cached=sum(s.num_cached_tokens for s in batch) if is_prefill else 0,
+                          ctx=sum(s.num_tokens for s in batch)))
+        sched.postprocess(batch, [7] * len(batch), is_prefill)
+    assert sched.block_manager.num_free == cfg.num_kvcache_blocks      # every block returned to the free list
+    return steps
+
+
+def test_config2_bench_workload_schedule_shape():
+    """BASELINE config 2 = the reference's bench.py (seed 0, 256 seqs, in/out U[100,1024]): totals and schedule
+    shape measured on the imported reference scheduler: 142,827 prompt tokens, 133,966
+    output tokens, 9 prefill + 1023 decode steps, 120.8 M decode token-reads."""
+    from random import randint, seed
+    seed(0)
+    prompts = [[randint(0, 10000) for _ in range(randint(100, 1024))] for _ in range(256)]
+    outs = [randint(100, 1024) for _ in range(256)]
+    assert sum(map(len, prompts)) == 142827 and sum(outs) == 133966
+    steps = _drive({}, prompts, outs)
+    pre = [s for s in steps if s["prefill"]]
+    dec = [s for s in steps if not s["prefill"]]
+    assert len(pre) == 9 and len(dec) == 1023
+    assert sum(s["ctx"] for s in dec) == 120795204
+    assert max(s["n"] for s in dec) == 256 and abs(sum(s["n"] for s in dec) / len(dec) - 130.7) < 0.5
+
+
+def test_config3_shared_system_prompt_prefix_cache():
+    """BASELINE config 3: a 512-token system prompt shared by 256 sequences. Block hashes are registered in
+    postprocess (scheduler.py:83), so the FIRST prefill batch shares nothing and every later sequence takes both
+    prefix blocks from the cache: cached tokens = (256 - first batch) * 512 (231 * 512 = 118,272
+    on the reference scheduler), 3 prefill steps, 127 decode steps at B = 256."""
+    from random import randint, seed
+    seed(0)
+    system = [randint(0, 10000) for _ in range(512)]
+    prompts = [system + [randint(0, 10000) for _ in range(randint(16, 256))] for _ in range(256)]
+    steps = _drive({}, prompts, [128] * 256)
+    pre = [s for s in steps if s["prefill"]]
+    dec = [s for s in steps if not s["prefill"]]
+    assert len(pre) == 3 and len(dec) == 127 and all(s["n"] == 256 for s in dec)
+    assert pre[0]["cached"] == 0
+    assert sum(s["cached"] for s in pre) == (256 - pre[0]["n"]) * 512
+    assert sum(s["sched"] + s["cached"] for s in pre) == sum(map(len, prompts))
+
+
+def test_config5_long_prefills_one_sequence_per_step():
+    """BASELINE config 5: 16 prompts of 16,000 tokens, max_num_batched_tokens 16,384 => 16 single-sequence prefill
+    steps (a second prompt never fits: only the first sequence of a batch may be chunked), 63 blocks each."""
+    prompts = [[(i * 7919 + j) % 10000 for j in range(16000)] for i in range(16)]
+    steps = _drive(dict(max_num_batched_tokens=16384, num_kvcache_blocks=30000), prompts, [64] * 16)
+    pre = [s for s in steps if s["prefill"]]
+    assert len(pre) == 16 and all(s["n"] == 1 and s["sched"] == 16000 for s in pre)
+    assert sum(1 for s in steps if not s["prefill"]) == 63
