@@ -117,6 +117,16 @@ def main():
         return n
 
     runner.prepare_decode = prepare_spy
+    orig_prepare_prefill = runner.prepare_prefill
+
+    def prepare_prefill_spy(seqs):
+        info = orig_prepare_prefill(seqs)
+        if rec["on"] and not info["paged"]:
+            st = runner.pstage.np
+            rec.setdefault("prefill", []).append(st["cu_q"][:info["ns"] + 1].copy())
+        return info
+
+    runner.prepare_prefill = prepare_prefill_spy
 
     # ---- host-side time of the timed pass (serial with the GPU: every step ends in a D2H sync) -----
     host = {"schedule_s": 0.0, "postprocess_s": 0.0, "prepare_decode_s": 0.0}
@@ -136,7 +146,10 @@ def main():
     runner.prepare_decode = timed(runner.prepare_decode, "prepare_decode_s")
 
     llm.generate(["Benchmark: "], SamplingParams(), use_tqdm=False)          # reference bench.py:22
+    # Every pass starts COLD, like the reference's single timed generate(): without the reset, pass k+1 would
+    # serve the full 256-token blocks of the same prompts from the prefix cache pass k left behind.
     for _ in range(args.warmup):
+        llm.reset_prefix_cache()
         llm.generate(prompts, sps, use_tqdm=False)
 
     def sync_all():
@@ -149,6 +162,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         rec["on"] = (k == args.steps - 1) and not args.no_roofline
+        llm.reset_prefix_cache()
         llm.generate(prompts, sps, use_tqdm=False)
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -184,6 +198,8 @@ def main():
     if rank == 0 and not args.no_roofline and rec["samples"]:
         result["config"]["host_seconds_in_last_step"] = {k: round(v, 4) for k, v in host.items()}
         result["roofline"] = roofline_replay(torch, runner, rec)
+        if rec.get("prefill"):
+            result["roofline_prefill"] = prefill_replay(torch, runner, rec["prefill"])
     if rank == 0 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(torch, llm, args.model, prompts, out_lens)
@@ -214,6 +230,40 @@ def roofline_replay(torch, runner, rec) -> dict:
             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],
             "launches_timed": r["launches_timed"], "decode_steps_in_pass": rec["steps"],
             "kv_bytes_read_in_pass": step_bytes, "frac_of_measured_achievable_6.29TBps": achieved / 6290.0}
+
+
+def prefill_replay(torch, runner, batches) -> dict:
+    """MFMA utilisation of the prefill-attention kernel on the prefill batches of the timed pass (their real
+    cu_seqlens; random q/k/v of the model's head geometry), HIP events on the launch stream.
+    FLOPs = 4 * Hq * 128 * causal (query, key) pairs — the algorithmic count, masked work not credited."""
+    from nano_vllm_amd import ops
+    geo = runner.geo
+    hq, hkv = geo["heads"], geo["kv_heads"]
+    dev = runner.device
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    flops, ms, launches = 0.0, 0.0, 0
+    for cu in batches:
+        n = int(cu[-1])
+        lens = (cu[1:] - cu[:-1]).astype("int64")
+        q = torch.randn(n, hq, 128, device=dev, dtype=torch.bfloat16)
+        k = torch.randn(n, hkv, 128, device=dev, dtype=torch.bfloat16)
+        v = torch.randn(n, hkv, 128, device=dev, dtype=torch.bfloat16)
+        cu_d = torch.from_numpy(cu.copy()).to(dev)
+        out = torch.empty_like(q)
+        for _ in range(2):
+            start.record()
+            for _ in range(4):
+                ops.attn_prefill_varlen(q, k, v, cu_d, cu_d, int(lens.max()), 128 ** -0.5, out=out)
+            stop.record()
+            torch.cuda.synchronize()
+        ms += start.elapsed_time(stop)
+        launches += 4
+        flops += 4 * 4.0 * hq * 128 * float((lens * (lens + 1) // 2).sum())
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
+            "traffic": None, "kernel": "prefill_attn_kernel<false> (nvl_attn_prefill_varlen)",
+            "avg_launch_us": ms * 1e3 / launches, "launches_timed": launches,
+            "note": "prefill batches of the timed pass (up to 16,384 tokens of 100-1024-token prompts per launch)"}
 
 
 def pmc_traffic(alg_bytes_per_launch: float):

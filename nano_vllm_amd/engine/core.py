@@ -73,6 +73,15 @@ class LLMEngine:
     def is_finished(self):
         return self.scheduler.is_finished()
 
+    def reset_prefix_cache(self):
+        """Forget every cached block (extension; engine must be idle). A second generate() over the same
+        prompts otherwise serves their full blocks from the prefix cache — which is the point of the cache,
+        but not what a cold-start measurement wants."""
+        assert self.scheduler.is_finished(), "reset_prefix_cache() needs an idle engine"
+        from .kv_blocks import BlockManager
+        bm = self.scheduler.block_manager
+        self.scheduler.block_manager = BlockManager(bm.num_blocks, bm.block_size)
+
     def generate(self, prompts, sampling_params, use_tqdm: bool = True):
         from tqdm.auto import tqdm
         pbar = tqdm(total=len(prompts), desc="Generating", dynamic_ncols=True, disable=not use_tqdm)
