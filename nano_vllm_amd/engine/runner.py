@@ -15,7 +15,7 @@ spec in SURVEY.md Appendix A.3), re-designed around the MI355X host/device bound
   * Block-table rows are rewritten only when a row's (sequence, #blocks) changed.
   * The whole decode step — 28 layers, lm_head and the sampler — is one hipGraph per batch
     bucket at TP=1 (the reference captures the layers only and runs lm_head + sampler eagerly).
-  * KV cache layout [2, L, num_blocks, Hkv, block, 128] (head-major blocks), zero-initialised;
+  * KV cache layout [L, 2, num_blocks, Hkv, block, 128] (layer-major, head-major blocks), zero-initialised;
     sized by the reference's formula (model_runner.py:103-115).
 """
 from __future__ import annotations
@@ -235,8 +235,13 @@ class ModelRunner:
             cfg.num_kvcache_blocks = int(total * cfg.gpu_memory_utilization - used - peak + current) // block_bytes
         assert cfg.num_kvcache_blocks > 0, "no memory left for the KV cache"
         # zero-filled: masked tail rows of a block are multiplied by P == 0 in the decode kernel
-        self.kv_cache = torch.zeros(2, geo["layers"], cfg.num_kvcache_blocks, geo["kv_heads"], self.block_size,
-                                    geo["head_dim"], dtype=torch.bfloat16, device=self.device)
+        # Layer-major: a layer's K and V pools sit next to each other (the reference's [2, L, ...] puts them
+        # 137 GB apart at this pool size, which costs the decode kernel 2.7 % of its bandwidth on MI355X —
+        # tools/attn_replay.py --cache-blocks 9377 [--layer-major]). `kv_cache` keeps the [2, L, ...] indexing
+        # as a transposed view.
+        self._kv_storage = torch.zeros(geo["layers"], 2, cfg.num_kvcache_blocks, geo["kv_heads"], self.block_size,
+                                       geo["head_dim"], dtype=torch.bfloat16, device=self.device)
+        self.kv_cache = self._kv_storage.transpose(0, 1)
         layer = 0
         for module in self.model.modules():
             if hasattr(module, "k_cache") and hasattr(module, "v_cache"):

@@ -118,16 +118,23 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--pool-blocks", type=int, default=9380, help="KV pool the schedule is recorded with")
     ap.add_argument("--fused", action="store_true", help="time nvl_paged_attn_decode_fused (norm+rope+store inside)")
+    ap.add_argument("--layer-major", action="store_true", help="cache laid out [L, 2, blocks, ...] instead of [2, L, blocks, ...]")
+    ap.add_argument("--cache-blocks", type=int, default=0,
+                    help="allocate the cache with this many blocks per layer (like the engine's pool) instead of only the used ones")
     args = ap.parse_args()
     import torch
     from nano_vllm_amd import ops
     ops.load_library()
     samples, stats = bench_decode_batches(num_blocks=args.pool_blocks, every=args.every)
-    nblk = stats["max_block"] + 1
+    used = stats["max_block"] + 1
+    nblk = max(used, args.cache_blocks)
     dev = torch.device("cuda", 0)
-    kv = torch.empty(2, args.layers, nblk, args.hkv, 256, 128, dtype=torch.bfloat16, device=dev)
+    if args.layer_major:
+        kv = torch.empty(args.layers, 2, nblk, args.hkv, 256, 128, dtype=torch.bfloat16, device=dev).transpose(0, 1)
+    else:
+        kv = torch.empty(2, args.layers, nblk, args.hkv, 256, 128, dtype=torch.bfloat16, device=dev)
     for layer in range(args.layers):               # random (not zero) data: zero-filled inputs clock higher
-        kv[:, layer].normal_()
+        kv[:, layer, :used].normal_()
     ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(512, args.hq, 4096), dtype=torch.uint8, device=dev)
     r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps, fused=args.fused)
     r.update(stats, kernel=f"decode_stream_kernel<{args.hq // args.hkv}, {str(args.fused).lower()}>", kv_blocks_used=nblk, samples=len(samples),
