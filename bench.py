@@ -128,7 +128,8 @@ def main():
 
     runner.prepare_prefill = prepare_prefill_spy
 
-    # ---- host-side time of the timed pass (serial with the GPU: every step ends in a D2H sync) -----
+    # ---- host-side time of the timed pass. With the decode lookahead (engine/core.py) schedule, postprocess
+    #      and prepare_decode of step N+1 run while the GPU executes step N; only fill_tokens is serial. -----
     host = {"schedule_s": 0.0, "postprocess_s": 0.0, "prepare_decode_s": 0.0}
 
     def timed(fn, key):
@@ -142,7 +143,8 @@ def main():
         return wrapper
 
     llm.scheduler.schedule = timed(llm.scheduler.schedule, "schedule_s")
-    llm.scheduler.postprocess = timed(llm.scheduler.postprocess, "postprocess_s")
+    llm.scheduler.postprocess = timed(llm.scheduler.postprocess, "postprocess_s")     # (postprocess_early calls it)
+    llm.scheduler.fill_tokens = timed(llm.scheduler.fill_tokens, "postprocess_s")
     runner.prepare_decode = timed(runner.prepare_decode, "prepare_decode_s")
 
     llm.generate(["Benchmark: "], SamplingParams(), use_tqdm=False)          # reference bench.py:22

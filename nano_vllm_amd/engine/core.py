@@ -8,6 +8,7 @@ submission order, dicts with "text" and "token_ids"), `exit`.
 from __future__ import annotations
 
 import atexit
+import os
 from dataclasses import fields
 from time import perf_counter
 
@@ -44,6 +45,9 @@ class LLMEngine:
         self.tokenizer = AutoTokenizer.from_pretrained(config.model, use_fast=True)
         config.eos = self.tokenizer.eos_token_id if self.tokenizer.eos_token_id is not None else -1
         self.scheduler = Scheduler(config)
+        # decode lookahead (see _step_lookahead): TP = 1 only (workers would need the split protocol);
+        # NVL_LOOKAHEAD=0 restores the strictly serial loop for A/B measurements
+        self._lookahead = config.tensor_parallel_size == 1 and os.environ.get("NVL_LOOKAHEAD", "1") != "0"
         self._exited = False
         atexit.register(self.exit)
 
@@ -70,6 +74,40 @@ class LLMEngine:
         outputs = [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
         return outputs, num_tokens
 
+    def _step_lookahead(self, pending):
+        """One engine step for `generate()`. Same results and the same sequence of scheduler / block-manager
+        operations as `step()`; when a decode step's bookkeeping does not depend on the sampled tokens
+        (all sequences ignore_eos, TP = 1) it is done — and the next step scheduled, and staged if it is such a
+        decode step too — while the GPU is still running the step, so the GPU only waits for the token ids to
+        be written into the next step's input ("overlap schedule(N+1) with GPU(N)").
+        `pending`: None, or (seqs, is_prefill, staged) scheduled by the previous call.
+        Returns (finished outputs, num_tokens, pending for the next call)."""
+        sched, runner = self.scheduler, self.model_runner
+        if pending is None:
+            seqs, is_prefill = sched.schedule()
+            staged = False
+        else:
+            seqs, is_prefill, staged = pending
+        num_tokens = sum(s.num_scheduled_tokens for s in seqs) if is_prefill else -len(seqs)
+        nxt = None
+        if self._lookahead and sched.can_lookahead(seqs, is_prefill):
+            runner.call("decode_begin", seqs, staged)
+            sched.postprocess_early(seqs)
+            if not sched.is_finished():
+                nseqs, nprefill = sched.schedule()
+                if sched.can_lookahead(nseqs, nprefill):
+                    runner.call("stage_next_decode", nseqs)
+                    nxt = (nseqs, False, True)
+                else:
+                    nxt = (nseqs, nprefill, False)
+            token_ids = runner.call("decode_end")
+            sched.fill_tokens(seqs, token_ids)
+        else:
+            token_ids = runner.call("run", seqs, is_prefill)
+            sched.postprocess(seqs, token_ids, is_prefill)
+        outputs = [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
+        return outputs, num_tokens, nxt
+
     def is_finished(self):
         return self.scheduler.is_finished()
 
@@ -91,9 +129,10 @@ class LLMEngine:
             self.add_request(prompt, sp)
         done: dict[int, list[int]] = {}
         prefill_tps = decode_tps = 0.0
-        while not self.is_finished():
+        pending = None                      # batch already scheduled (and maybe staged) by the lookahead
+        while not self.is_finished() or pending is not None:
             t0 = perf_counter()
-            finished, num_tokens = self.step()
+            finished, num_tokens, pending = self._step_lookahead(pending)
             dt = perf_counter() - t0
             if num_tokens > 0:
                 prefill_tps = num_tokens / dt

@@ -207,6 +207,8 @@ class ModelRunner:
         self.hidden_out = (torch.zeros(mb, self.geo["hidden"], dtype=torch.bfloat16, device=self.device)
                            if self.world_size > 1 else None)
         self.step_count = 0
+        self._inflight = 0
+        self._upload_done = torch.cuda.Event()
 
     # ------------------------------------------------------------------ warm-up + KV cache
     def warmup_model(self):
@@ -367,10 +369,19 @@ class ModelRunner:
         reset_context()
 
     @torch.inference_mode()
-    def _run_decode(self, seqs: list[Sequence]) -> list[int] | None:
-        n = self.prepare_decode(seqs)
+    def decode_begin(self, seqs: list[Sequence], staged: bool = False) -> int:
+        """Enqueue one decode step (H2D of the staging block, graph replay or eager forward, D2H of the
+        sampled ids) and return without waiting. `staged`: the staging block was already filled by
+        `prepare_decode` (lookahead) and only the input ids — unknown until the previous step's tokens
+        arrived — are written now."""
+        if staged:
+            n = len(seqs)
+            self.dstage.np["ids"][:n] = [s.last_token for s in seqs]
+        else:
+            n = self.prepare_decode(seqs)
         self._next_rng(self.dstage)
         self.dstage.upload()
+        self._upload_done.record()
         bucket = next((b for b in self.graph_bs if b >= n), None) if self.graphs else None
         if bucket is not None:
             self.graphs[bucket].replay()
@@ -378,11 +389,28 @@ class ModelRunner:
             self._forward_decode(n)
         if self.world_size > 1:
             self._decode_tail(n)
-        if self.rank != 0:
-            return None
-        self.tokens_host[:n].copy_(self.tokens_dev[:n], non_blocking=True)
+        if self.rank == 0:
+            self.tokens_host[:n].copy_(self.tokens_dev[:n], non_blocking=True)
+        self._inflight = n
+        return n
+
+    def decode_end(self) -> list[int] | None:
+        """Wait for the step enqueued by `decode_begin` and return its sampled ids (rank 0)."""
+        n = self._inflight
+        self._inflight = 0
         torch.cuda.current_stream().synchronize()
-        return self.tokens_host[:n].tolist()
+        return self.tokens_host[:n].tolist() if self.rank == 0 else None
+
+    def stage_next_decode(self, seqs: list[Sequence]) -> None:
+        """Lookahead: fill the staging block for the NEXT decode step while the current one runs on the GPU
+        (everything but the input ids). The pinned block is free again once the current step's upload has
+        been consumed."""
+        self._upload_done.synchronize()
+        self.prepare_decode(seqs)
+
+    def _run_decode(self, seqs: list[Sequence]) -> list[int] | None:
+        self.decode_begin(seqs)
+        return self.decode_end()
 
     @torch.inference_mode()
     def _run_prefill(self, seqs: list[Sequence]) -> list[int] | None:

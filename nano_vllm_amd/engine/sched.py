@@ -100,6 +100,26 @@ class Scheduler:
         self.block_manager.deallocate(seq)
         self.waiting.appendleft(seq)
 
+    # --- lookahead form of postprocess for decode steps whose outcome does not depend on the sampled
+    # tokens (every sequence has ignore_eos): `postprocess_early` does everything `postprocess` does except
+    # write the token values, in the same order (hash -> count -> finish/deallocate), so the block manager
+    # goes through exactly the reference's states; `fill_tokens` writes the values once they are on the host.
+    # The engine uses the gap to schedule and stage step N+1 while the GPU still runs step N.
+    PLACEHOLDER = -1
+
+    @staticmethod
+    def can_lookahead(seqs: list[Sequence], is_prefill: bool) -> bool:
+        return (not is_prefill) and all(s.ignore_eos for s in seqs)
+
+    def postprocess_early(self, seqs: list[Sequence]) -> None:
+        self.postprocess(seqs, [self.PLACEHOLDER] * len(seqs), False)
+
+    @staticmethod
+    def fill_tokens(seqs: list[Sequence], token_ids: list[int]) -> None:
+        for seq, token_id in zip(seqs, token_ids):
+            seq.token_ids[-1] = token_id          # the placeholder is still the last element: fill precedes the
+            seq.last_token = token_id             # next step's early postprocess
+
     def postprocess(self, seqs: list[Sequence], token_ids: list[int], is_prefill: bool) -> None:
         bm = self.block_manager
         finished = False

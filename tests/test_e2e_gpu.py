@@ -26,12 +26,24 @@ def _run_ours(path, prompts, max_tokens, **kw):
     runner = llm.model_runner
     orig = runner.call
 
+    def snap(seqs, is_prefill):
+        return dict(prefill=is_prefill, seq_ids=[s.seq_id for s in seqs], tables=[list(s.block_table) for s in seqs],
+                    sched=[s.num_scheduled_tokens for s in seqs])
+
+    open_step = []
+
     def spy(method, *args):
+        # a step is either one "run" call or a "decode_begin" ... "decode_end" pair (decode lookahead);
+        # batch composition and block tables are snapshotted when the step is issued
+        if method == "decode_begin":
+            open_step.append(snap(args[0], False))
+        elif method == "run":
+            open_step.append(snap(*args))
         out = orig(method, *args)
-        if method == "run":
-            seqs, is_prefill = args
-            rec.append(dict(prefill=is_prefill, tokens=list(out), seq_ids=[s.seq_id for s in seqs],
-                            tables=[list(s.block_table) for s in seqs], sched=[s.num_scheduled_tokens for s in seqs]))
+        if method in ("run", "decode_end"):
+            step = open_step.pop()
+            step["tokens"] = list(out)
+            rec.append(step)
         return out
 
     runner.call = spy
@@ -256,7 +268,7 @@ def test_logits_close_to_oracle(tiny_ckpt):
 
     def spy(method, *args):
         out = call(method, *args)
-        if method == "run":
+        if method in ("run", "decode_end"):
             toks.append(list(out))
         return out
 
