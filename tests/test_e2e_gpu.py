@@ -291,3 +291,26 @@ def test_logits_close_to_oracle(tiny_ckpt):
         worst = max(worst, rel)
     print(f"logits max|diff|/absmax over {len(ours)} steps: {worst:.5f}")
     assert worst <= 2e-2
+
+
+def test_lookahead_and_microbatch_modes_reproduce_the_serial_engine(tiny_ckpt, monkeypatch):
+    """Host-loop variants must not change results: the decode lookahead (default) vs the strictly serial loop
+    (NVL_LOOKAHEAD=0), and the optional two-chain micro-batched decode graph (NVL_MICROBATCHES=2) — same sampled
+    tokens at T=0.8 with a fixed seed (same Philox offsets per step), 40 sequences so that the micro-batched
+    graphs (batch >= 32) are exercised. (The micro-batched sampler seeds its second chain differently, so it is
+    compared at T=0.)"""
+    from nano_vllm_amd import LLM, SamplingParams
+    prompts = _prompts(40, 5, 300, 512, seed=31)
+
+    def run(temp, **env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        llm = LLM(tiny_ckpt, enforce_eager=False, max_model_len=2048, num_kvcache_blocks=96, max_num_seqs=64, seed=7)
+        outs = llm.generate(prompts, SamplingParams(temperature=temp, max_tokens=10, ignore_eos=True), use_tqdm=False)
+        llm.exit()
+        for k in env:
+            monkeypatch.delenv(k)
+        return [o["token_ids"] for o in outs]
+
+    assert run(0.8) == run(0.8, NVL_LOOKAHEAD="0")
+    assert run(0.0) == run(0.0, NVL_MICROBATCHES="2")
