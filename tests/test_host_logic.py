@@ -257,3 +257,50 @@ def test_config5_long_prefills_one_sequence_per_step():
     pre = [s for s in steps if s["prefill"]]
     assert len(pre) == 16 and all(s["n"] == 1 and s["sched"] == 16000 for s in pre)
     assert sum(1 for s in steps if not s["prefill"]) == 63
+
+
+def test_lookahead_order_reproduces_serial_schedule():
+    """engine/core.py::_step_lookahead runs postprocess_early(N) -> schedule(N+1) -> fill_tokens(N) instead of
+    postprocess(N) -> schedule(N+1). With ignore_eos everywhere the two orders must produce identical batches,
+    block tables, cached-token counts and final token lists — including under block-pool pressure (preemption,
+    re-prefill of a preempted sequence whose last token was still a placeholder when it was preempted)."""
+    from random import Random
+    from types import SimpleNamespace
+    from nano_vllm_amd.api import SamplingParams
+    from nano_vllm_amd.engine.sched import Scheduler
+    from nano_vllm_amd.engine.seq import Sequence
+    from oracle.host_trace import fake_token
+
+    def run(lookahead: bool):
+        rnd = Random(5)
+        cfg = SimpleNamespace(max_num_seqs=16, max_num_batched_tokens=2048, eos=-1, kvcache_block_size=256,
+                              num_kvcache_blocks=26)
+        Sequence.block_size = 256
+        sched = Scheduler(cfg)
+        seqs = [Sequence([rnd.randrange(8, 5000) for _ in range(rnd.randrange(1, 700))],
+                         SamplingParams(temperature=1.0, max_tokens=rnd.randrange(1, 500), ignore_eos=True)) for _ in range(24)]
+        index = {id(s): i for i, s in enumerate(seqs)}
+        for s in seqs:
+            sched.add(s)
+        trace, pending, preempted = [], None, 0
+        while not sched.is_finished() or pending is not None:
+            batch, is_prefill = pending if pending is not None else sched.schedule()
+            pending = None
+            tokens = [fake_token(index[id(s)], len(s)) for s in batch]
+            trace.append((is_prefill, [index[id(s)] for s in batch], [list(s.block_table) for s in batch],
+                          [s.num_cached_tokens for s in batch], [s.num_scheduled_tokens for s in batch]))
+            if lookahead and sched.can_lookahead(batch, is_prefill):
+                sched.postprocess_early(batch)
+                if not sched.is_finished():
+                    pending = sched.schedule()
+                sched.fill_tokens(batch, tokens)
+            else:
+                sched.postprocess(batch, tokens, is_prefill)
+        preempted = sum(1 for t in trace if t[0])      # prefill steps beyond the initial ones imply re-prefills
+        return trace, [s.token_ids for s in seqs], preempted
+
+    serial, toks_a, pre_a = run(False)
+    ahead, toks_b, pre_b = run(True)
+    assert serial == ahead and toks_a == toks_b
+    assert all(t != -1 for toks in toks_b for t in toks)
+    assert pre_a > 3                                   # the pool is small enough to force preemption + re-prefill
