@@ -377,6 +377,24 @@ def test_prefill_contiguous(ops, hq, hkv, lens):
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
 
 
+def test_prefill_many_short_sequences(ops):
+    """600 sequences of 1-70 tokens in one launch: the on-device (sequence, q-block) lookup runs its prefix scan
+    in several 256-wide rounds, most tiles are partial, and the last sequence ends exactly at the end of the K/V
+    tensors (the buffer descriptors' range check, not a clamp, keeps the partial tiles in bounds)."""
+    gen = g(44)
+    lens = torch.randint(1, 71, (600,), generator=gen).tolist()
+    n, hq, hkv = sum(lens), 4, 2
+    q = torch.randn(n, hq, 128, generator=gen).to(BF16)
+    k = torch.randn(n, hkv, 128, generator=gen).to(BF16)
+    v = torch.randn(n, hkv, 128, generator=gen).to(BF16)
+    cu = _cu(lens)
+    scale = 128 ** -0.5
+    o_ref = ref.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, scale, True, None)
+    o = ops.attn_prefill_varlen(dev(q), dev(k), dev(v), dev(cu), dev(cu), max(lens), scale)
+    err = (o.cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+
+
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1)])
 @pytest.mark.parametrize("lq_lk", [[(1, 257)], [(100, 356), (256, 256), (7, 1031)], [(300, 812), (64, 64)]])
 def test_prefill_paged_prefix(ops, hq, hkv, lq_lk):
