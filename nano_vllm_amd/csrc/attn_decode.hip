@@ -544,32 +544,48 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
                                                                      const int32_t* __restrict__ ctx,
                                                                      bf16_t* __restrict__ out, int hq, int hkv,
                                                                      int slots) {
-  // out[b, head, :] = sum_k 2^(m_k - M) O_k / sum_k 2^(m_k - M) l_k over the (b, h) segment's
-  // split partials; zero rows when the sequence is padding. Loads are issued independently
-  // (one (m, l) pair per thread, then all O rows) so the kernel is ~2 memory latencies long.
-  __shared__ float sm[128], sl[128];
+  // out[b, head, :] = sum_k 2^(m_k - M) O_k / sum_k 2^(m_k - M) l_k over the (b, h) segment's split partials;
+  // zero rows when the sequence is padding. The kernel is pure latency (a few KB per block), so everything a
+  // typical segment needs — the count, and the first kSpec (m, l, O) slots — is loaded SPECULATIVELY in one
+  // round (the slots exist in the workspace whatever the count; unused ones are never used in arithmetic);
+  // only segments split over more than kSpec waves take a second round.
+  constexpr int kSpec = 6;
   const int b = blockIdx.x / hq;
   const int head = blockIdx.x - b * hq;
   const int64_t row = blockIdx.x;
-  const int cnt = ctx[b] > 0 ? meta[b * hkv + head / (hq / hkv)] : 0;
   const int d = threadIdx.x;
   const float* ml = part_ml + row * slots * 2;
   const float* po = part_o + row * slots * 128;
-  for (int c = d; c < cnt; c += 128) {   // cnt <= slots (34 at max_context 4096)
-    sm[c % 128] = ml[c * 2];
-    sl[c % 128] = ml[c * 2 + 1];
+  const int len = ctx[b];
+  const int cnt_raw = meta[b * hkv + head / (hq / hkv)];
+  float m_s[kSpec], l_s[kSpec], o_s[kSpec];
+#pragma unroll
+  for (int c = 0; c < kSpec; ++c) {
+    const int cc = c < slots ? c : 0;
+    m_s[c] = ml[cc * 2];
+    l_s[c] = ml[cc * 2 + 1];
+    o_s[c] = po[cc * 128 + d];
   }
-  __syncthreads();
-  const int n = cnt < 128 ? cnt : 128;
+  const int cnt = len > 0 ? cnt_raw : 0;
   float M = kNegBig;
-  for (int c = 0; c < n; ++c) M = fmaxf(M, sm[c]);
+#pragma unroll
+  for (int c = 0; c < kSpec; ++c)
+    if (c < cnt) M = fmaxf(M, m_s[c]);
+  for (int c = kSpec; c < cnt; ++c) M = fmaxf(M, ml[c * 2]);
   float num = 0.f, den = 0.f;
-  for (int c = 0; c < n; ++c) {
-    const float f = exp2f(sm[c] - M);
+#pragma unroll
+  for (int c = 0; c < kSpec; ++c)
+    if (c < cnt) {
+      const float f = exp2f(m_s[c] - M);
+      num += f * o_s[c];
+      den += f * l_s[c];
+    }
+  for (int c = kSpec; c < cnt; ++c) {
+    const float f = exp2f(ml[c * 2] - M);
     num += f * po[c * 128 + d];
-    den += f * sl[c];
+    den += f * ml[c * 2 + 1];
   }
-  out[row * 128 + d] = (bf16_t)(n > 0 ? num / den : 0.f);
+  out[row * 128 + d] = (bf16_t)(cnt > 0 ? num / den : 0.f);
 }
 
 inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 2; }
