@@ -8,10 +8,15 @@ is arranged for MI355X:
    add+RMSNorm -> gate_up GEMM -> SiLU*mul -> down GEMM (+all-reduce)
 
 i.e. 10 launches per layer instead of the reference's 13 (each dependent kernel boundary is
-~1.5 us on this chip even inside a hipGraph — MI355X_MICROARCH.md "boundary"). On decode-sized
-batches (<= 256 rows, TP=1) the GEMMs are the hand-written skinny kernels (nvl_linear_decode):
-SiLU*mul becomes the gate_up epilogue and o/down emit fp32 split-K partials that the next
-add+RMSNorm sums in its prologue — 9 launches per layer.
+~1.5 us on this chip even inside a hipGraph — MI355X_MICROARCH.md "boundary"; a small dependent
+kernel costs ~5 us whatever it does). On decode-sized batches (<= 256 rows, TP=1, single-K-pass
+shapes) the chain is 8 launches:
+
+   add+RMSNorm(fp32 slabs) -> qkv GEMM -> [q/k-norm + RoPE + KV store + paged attention: ONE launch]
+   -> split merge -> o GEMM (fp32 split-K slabs) -> add+RMSNorm(slabs) -> gate_up GEMM + SiLU*mul epilogue
+   -> down GEMM (slabs)
+
+with the GEMMs on the hand-written skinny kernel (nvl_linear_decode).
 """
 from __future__ import annotations
 
