@@ -45,6 +45,21 @@ def test_host_side_argument_validation_without_gpu():
     assert rc == -1 and b"null pointer" in lib.nvl_last_error()
     rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 16, 6, 256, 8, 4096, 0.1, 16, 1 << 30, None)
     assert rc == -1 and b"not a multiple" in lib.nvl_last_error()
+    # fused decode entry: rope table is mandatory; q/k norm weights come as a pair
+    rc = lib.nvl_paged_attn_decode_fused(16, 4096, None, None, 1e-6, None, 0, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
+                                         4096, 0.1, 16, 1 << 30, None)
+    assert rc == -1 and b"rope table" in lib.nvl_last_error()
+    rc = lib.nvl_paged_attn_decode_fused(16, 4096, 16, None, 1e-6, 16, 4096, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
+                                         4096, 0.1, 16, 1 << 30, None)
+    assert rc == -1 and b"both be set or both NULL" in lib.nvl_last_error()
+    # skinny linear: shape coverage is a query, an uncovered shape is EUNSUPPORTED (-3), never a silent fallback
+    assert lib.nvl_linear_decode_splits(144, 4096, 1024, 0) == 1
+    assert lib.nvl_linear_decode_splits(144, 1024, 2048, 2) == 4
+    assert lib.nvl_linear_decode_splits(144, 6144, 1024, 1) == 1
+    assert lib.nvl_linear_decode_splits(144, 6144, 4096, 0) == 0
+    assert lib.nvl_linear_decode(16, 16, 16, 144, 6144, 4096, 0, None) == -3 and b"not covered" in lib.nvl_last_error()
+    assert lib.nvl_linear_decode(None, 16, 16, 144, 4096, 1024, 0, None) == -1
+    assert lib.nvl_add_rmsnorm_splitk(16, 0, 16, 16, 16, 4, 1024, 1e-6, None) == -1 and b"splits" in lib.nvl_last_error()
 
 
 def test_no_product_import_of_the_oracle():
