@@ -106,8 +106,8 @@ def main():
     rec = {"on": False, "steps": 0, "ctx_tokens": 0, "samples": []}
     orig_prepare = runner.prepare_decode
 
-    def prepare_spy(seqs):
-        n = orig_prepare(seqs)
+    def prepare_spy(seqs, *a):
+        n = orig_prepare(seqs, *a)
         if rec["on"]:
             st = runner.dstage.np
             rec["ctx_tokens"] += int(st["ctx"][:n].sum())

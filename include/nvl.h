@@ -245,6 +245,16 @@ int nvl_sample(const void* logits, int64_t logits_row_stride,
                uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Feed the previous step's sampled ids back as this step's input ids ON THE DEVICE:
+ *   ids[i] = src_row[i] >= 0 ? prev_tokens[src_row[i]] : ids[i]
+ * The reference round-trips every sampled id through the host (`.tolist()` at
+ * engine/model_runner.py:218, then `torch.tensor(input_ids...)` at :183 on the next
+ * step); with this node at the head of the captured decode graph the engine can
+ * enqueue step N+1 before step N's ids have reached the host. src_row: int32 [n]
+ * (row of the sequence in the previous decode batch, -1 = take the staged id). */
+int nvl_feed_tokens(int64_t* ids, const int32_t* src_row, const int64_t* prev_tokens,
+                    int64_t n, void* stream);
+
 /* Host-side reference of the sampler's RNG (same Philox stream as the
  * kernel): fills e[n] with the Exp(1) draws for columns [col0, col0+n) of
  * `row`. Lets tests replay a GPU draw bit-exactly on the CPU. */

@@ -144,6 +144,27 @@ extern "C" int nvl_sample(const void* logits, int64_t logits_row_stride, const f
   return nvl_check_launch("nvl_sample");
 }
 
+namespace {
+__global__ __launch_bounds__(256) void feed_tokens_kernel(int64_t* __restrict__ ids, const int32_t* __restrict__ src,
+                                                          const int64_t* __restrict__ prev, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int32_t r = src[i];
+    if (r >= 0) ids[i] = prev[r];
+  }
+}
+}  // namespace
+
+extern "C" int nvl_feed_tokens(int64_t* ids, const int32_t* src_row, const int64_t* prev_tokens, int64_t n,
+                               void* stream) {
+  NVL_REQUIRE(ids && src_row && prev_tokens, "nvl_feed_tokens: null pointer");
+  NVL_REQUIRE(n >= 0 && n < (1ll << 31), "nvl_feed_tokens: bad n=%lld", (long long)n);
+  if (n == 0) return NVL_OK;
+  hipLaunchKernelGGL(feed_tokens_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids,
+                     src_row, prev_tokens, n);
+  return nvl_check_launch("nvl_feed_tokens");
+}
+
 extern "C" void nvl_sample_exponentials_host(uint64_t seed, uint64_t offset, int64_t row, int64_t col0, int64_t n,
                                              float* e_host) {
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);

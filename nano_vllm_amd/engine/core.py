@@ -48,6 +48,7 @@ class LLMEngine:
         # decode lookahead (see _step_lookahead): TP = 1 only (workers would need the split protocol);
         # NVL_LOOKAHEAD=0 restores the strictly serial loop for A/B measurements
         self._lookahead = config.tensor_parallel_size == 1 and os.environ.get("NVL_LOOKAHEAD", "1") != "0"
+        self._unfilled = None              # sequences of an in-flight lookahead step whose token values are pending
         self._exited = False
         atexit.register(self.exit)
 
@@ -74,25 +75,43 @@ class LLMEngine:
         outputs = [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
         return outputs, num_tokens
 
+    def _collect(self):
+        """Bring the oldest in-flight decode step's ids to the host and write them into its sequences."""
+        seqs = self._unfilled
+        self._unfilled = None
+        if seqs is None:
+            return []
+        self.scheduler.fill_tokens(seqs, self.model_runner.call("decode_end"))
+        return [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
+
     def _step_lookahead(self, pending):
         """One engine step for `generate()`. Same results and the same sequence of scheduler / block-manager
-        operations as `step()`; when a decode step's bookkeeping does not depend on the sampled tokens
-        (all sequences ignore_eos, TP = 1) it is done — and the next step scheduled, and staged if it is such a
-        decode step too — while the GPU is still running the step, so the GPU only waits for the token ids to
-        be written into the next step's input ("overlap schedule(N+1) with GPU(N)").
+        operations as `step()`; when a decode step's bookkeeping does not depend on the sampled tokens (all
+        sequences ignore_eos, TP = 1) the host runs ahead of the GPU ("overlap
+        schedule(N+1) with GPU(N)"): step N+1 is ENQUEUED before step N's ids have reached the host — its
+        input ids are taken from step N's output on the device (nvl_feed_tokens) — then step N is collected,
+        and postprocess (token values filled in afterwards), schedule and staging of step N+2 run while the
+        GPU works. The GPU queue never drains between decode steps. Finished sequences of a lookahead step
+        are reported by the next call.
         `pending`: None, or (seqs, is_prefill, staged) scheduled by the previous call.
         Returns (finished outputs, num_tokens, pending for the next call)."""
         sched, runner = self.scheduler, self.model_runner
         if pending is None:
+            outputs = self._collect()                    # nothing staged: the schedule may need real tokens
+            if sched.is_finished():
+                return outputs, 0, None
             seqs, is_prefill = sched.schedule()
             staged = False
         else:
+            outputs = []
             seqs, is_prefill, staged = pending
         num_tokens = sum(s.num_scheduled_tokens for s in seqs) if is_prefill else -len(seqs)
         nxt = None
         if self._lookahead and sched.can_lookahead(seqs, is_prefill):
             runner.call("decode_begin", seqs, staged)
+            outputs += self._collect()                   # the previous decode step, now that the GPU has work queued
             sched.postprocess_early(seqs)
+            self._unfilled = seqs
             if not sched.is_finished():
                 nseqs, nprefill = sched.schedule()
                 if sched.can_lookahead(nseqs, nprefill):
@@ -100,12 +119,11 @@ class LLMEngine:
                     nxt = (nseqs, False, True)
                 else:
                     nxt = (nseqs, nprefill, False)
-            token_ids = runner.call("decode_end")
-            sched.fill_tokens(seqs, token_ids)
         else:
+            outputs += self._collect()
             token_ids = runner.call("run", seqs, is_prefill)
             sched.postprocess(seqs, token_ids, is_prefill)
-        outputs = [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
+            outputs += [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
         return outputs, num_tokens, nxt
 
     def is_finished(self):
@@ -130,7 +148,7 @@ class LLMEngine:
         done: dict[int, list[int]] = {}
         prefill_tps = decode_tps = 0.0
         pending = None                      # batch already scheduled (and maybe staged) by the lookahead
-        while not self.is_finished() or pending is not None:
+        while not self.is_finished() or pending is not None or self._unfilled is not None:
             t0 = perf_counter()
             finished, num_tokens, pending = self._step_lookahead(pending)
             dt = perf_counter() - t0

@@ -46,7 +46,7 @@ def _align(n: int, a: int = 16) -> int:
 class _Stage:
     """Fixed-layout staging block: pinned host copy + device copy + typed views of both."""
 
-    def __init__(self, fields: list[tuple[str, np.dtype, tuple]], device):
+    def __init__(self, fields: list[tuple[str, np.dtype, tuple]], device, host_copies: int = 1):
         off = 0
         layout = []
         for name, dt, shape in fields:
@@ -55,20 +55,42 @@ class _Stage:
             off = _align(off + nbytes)
         self.nbytes = off
         pin = device.type == "cuda"
-        self.host = torch.zeros(off, dtype=torch.uint8, device="cpu", pin_memory=pin)
+        # `host_copies` pinned host images (the decode stage keeps two: step N+1 is staged while the upload of
+        # step N may still be queued behind the GPU work of step N-1); `np` / `host` always name the current one
+        self.hosts = [torch.zeros(off, dtype=torch.uint8, device="cpu", pin_memory=pin) for _ in range(host_copies)]
         self.dev = torch.zeros(off, dtype=torch.uint8, device=device)
-        hnp = self.host.numpy()
-        self.np: dict[str, np.ndarray] = {}
+        self.nps: list[dict[str, np.ndarray]] = []
         self.t: dict[str, torch.Tensor] = {}
         tdt = {np.dtype(np.int64): torch.int64, np.dtype(np.int32): torch.int32, np.dtype(np.float32): torch.float32,
                np.dtype(np.uint64): torch.int64}
+        for h in self.hosts:
+            hnp = h.numpy()
+            self.nps.append({name: hnp[o:o + nb].view(dt).reshape(shape) for name, dt, shape, o, nb in layout})
         for name, dt, shape, o, nb in layout:
-            self.np[name] = hnp[o:o + nb].view(dt).reshape(shape)
             self.t[name] = self.dev[o:o + nb].view(tdt[dt]).view(shape)
+        self.uploaded = [torch.cuda.Event() if pin else None for _ in self.hosts]
+        self.cur = 0
+
+    @property
+    def np(self) -> dict[str, np.ndarray]:
+        return self.nps[self.cur]
+
+    @property
+    def host(self) -> torch.Tensor:
+        return self.hosts[self.cur]
+
+    def flip(self) -> None:
+        """Switch to the other pinned image and make sure its last upload has been consumed."""
+        self.cur = (self.cur + 1) % len(self.hosts)
+        ev = self.uploaded[self.cur]
+        if ev is not None:
+            ev.synchronize()
 
     def upload(self, nbytes: int | None = None) -> None:
         n = self.nbytes if nbytes is None else nbytes
         self.dev[:n].copy_(self.host[:n], non_blocking=True)
+        if self.uploaded[self.cur] is not None:
+            self.uploaded[self.cur].record()
 
 
 class ModelRunner:
@@ -184,13 +206,16 @@ class ModelRunner:
         self.dstage = _Stage([
             ("ids", np.int64, (mb,)), ("pos", np.int64, (mb,)), ("rng", np.uint64, (2,)),
             ("slots", np.int32, (mb,)), ("ctx", np.int32, (mb,)), ("temps", np.float32, (mb,)),
-            ("bt", np.int32, (mb, w)),
-        ], self.device)
-        self.dstage.np["slots"][:] = -1
-        self.dstage.np["bt"][:] = -1
+            ("src", np.int32, (mb,)), ("bt", np.int32, (mb, w)),
+        ], self.device, host_copies=2)
+        for image in self.dstage.nps:
+            image["slots"][:] = -1
+            image["bt"][:] = -1
+            image["src"][:] = -1
         self.dstage.upload()
-        self._row_key = np.full((mb, 2), -1, dtype=np.int64)     # (seq id, #blocks) per decode row
-        self._dirty_rows = 0
+        # per pinned image: (seq id, #blocks) per decode row whose block-table row is current, rows in use
+        self._row_keys = [np.full((mb, 2), -1, dtype=np.int64) for _ in self.dstage.nps]
+        self._dirty = [0 for _ in self.dstage.nps]
         nt = cfg.max_num_batched_tokens
         ns = min(cfg.max_num_seqs, nt)
         self.pstage = _Stage([
@@ -200,6 +225,7 @@ class ModelRunner:
         ], self.device)
         self.tokens_dev = torch.zeros(max(mb, ns), dtype=torch.int64, device=self.device)
         self.tokens_host = torch.zeros(max(mb, ns), dtype=torch.int64, device="cpu", pin_memory=True)
+        self.tokens_host_b = torch.zeros(max(mb, ns), dtype=torch.int64, device="cpu", pin_memory=True)
         ws_bytes = ops.paged_attn_decode_workspace_bytes(mb, self.geo["heads"], cfg.max_model_len)
         # zeroed once: the kernel's arrival counters live in it and are left at zero by every launch
         self.decode_ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
@@ -207,8 +233,10 @@ class ModelRunner:
         self.hidden_out = (torch.zeros(mb, self.geo["hidden"], dtype=torch.bfloat16, device=self.device)
                            if self.world_size > 1 else None)
         self.step_count = 0
-        self._inflight = 0
-        self._upload_done = torch.cuda.Event()
+        self._inflight: list = []            # decode steps enqueued and not yet collected (at most two)
+        self._flight_parity = 0
+        self._step_done = [torch.cuda.Event(), torch.cuda.Event()]
+        self._last_rows: dict = {}
 
     # ------------------------------------------------------------------ warm-up + KV cache
     def warmup_model(self):
@@ -287,19 +315,26 @@ class ModelRunner:
                 bt[i, len(t):] = -1
         return dict(n=n, ns=ns, max_q=max_q, max_k=max_k, paged=paged, have_slots=have_slots)
 
-    def prepare_decode(self, seqs: list[Sequence]) -> int:
-        """Fill the decode staging block (semantics of model_runner.py:172-188); returns bs."""
+    def prepare_decode(self, seqs: list[Sequence], prev_rows: dict | None = None) -> int:
+        """Fill the current pinned decode image (semantics of model_runner.py:172-188); returns bs.
+        `prev_rows` (lookahead): seq_id -> row of the sequence in the decode step that is still in flight; the
+        input ids are then NOT staged — the graph's first node copies them from that step's sampled ids on the
+        device (nvl_feed_tokens) — and `src` carries the rows."""
         st, bs = self.dstage.np, self.block_size
         n = len(seqs)
         lens = np.fromiter((s.num_tokens for s in seqs), dtype=np.int64, count=n)
-        st["ids"][:n] = [s.last_token for s in seqs]
+        if prev_rows is None:
+            st["ids"][:n] = [s.last_token for s in seqs]
+            st["src"][:n] = -1
+        else:
+            st["src"][:n] = [prev_rows[s.seq_id] for s in seqs]
         st["pos"][:n] = lens - 1
         st["ctx"][:n] = lens
         last_blk = np.fromiter((s.block_table[-1] for s in seqs), dtype=np.int64, count=n)
         st["slots"][:n] = last_blk * bs + (lens - 1) % bs
         st["temps"][:n] = [s.temperature for s in seqs]
-        # block tables: rewrite a row only when its (sequence, #blocks) changed
-        key = self._row_key
+        # block tables: rewrite a row only when its (sequence, #blocks) changed in THIS image
+        key = self._row_keys[self.dstage.cur]
         ids = np.fromiter((s.seq_id for s in seqs), dtype=np.int64, count=n)
         nblk = np.fromiter((len(s.block_table) for s in seqs), dtype=np.int64, count=n)
         stale = np.nonzero((key[:n, 0] != ids) | (key[:n, 1] != nblk) | (ids < 0))[0]
@@ -310,11 +345,12 @@ class ModelRunner:
             bt[i, len(t):] = -1
         key[:n, 0], key[:n, 1] = ids, nblk
         # neutralise rows used by a previous, larger batch (graph padding: slot -1, context 0)
-        if self._dirty_rows > n:
-            st["slots"][n:self._dirty_rows] = -1
-            st["ctx"][n:self._dirty_rows] = 0
-            key[n:self._dirty_rows] = -1
-        self._dirty_rows = n
+        dirty = self._dirty[self.dstage.cur]
+        if dirty > n:
+            st["slots"][n:dirty] = -1
+            st["ctx"][n:dirty] = 0
+            key[n:dirty] = -1
+        self._dirty[self.dstage.cur] = n
         return n
 
     # ------------------------------------------------------------------ forward
@@ -327,6 +363,8 @@ class ModelRunner:
         t = self.dstage.t
         set_context(False, slot_mapping=t["slots"][r0:r1], context_lens=t["ctx"][r0:r1],
                     block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len)
+        # input ids of sequences that were in the previous decode step come straight from its sampled ids
+        ops.feed_tokens(t["ids"][r0:r1], t["src"][r0:r1], self.tokens_dev)
         hidden = self.model(t["ids"][r0:r1], t["pos"][r0:r1])
         if self.world_size == 1:
             logits = self.model.compute_logits(hidden)
@@ -370,18 +408,15 @@ class ModelRunner:
 
     @torch.inference_mode()
     def decode_begin(self, seqs: list[Sequence], staged: bool = False) -> int:
-        """Enqueue one decode step (H2D of the staging block, graph replay or eager forward, D2H of the
-        sampled ids) and return without waiting. `staged`: the staging block was already filled by
-        `prepare_decode` (lookahead) and only the input ids — unknown until the previous step's tokens
-        arrived — are written now."""
-        if staged:
-            n = len(seqs)
-            self.dstage.np["ids"][:n] = [s.last_token for s in seqs]
-        else:
-            n = self.prepare_decode(seqs)
+        """Enqueue one decode step (H2D of the staging image, graph replay or eager forward, D2H of the
+        sampled ids) and return without waiting; up to two steps may be in flight. `staged`: the image was
+        already filled by `stage_next_decode` (lookahead)."""
+        if not staged:
+            self.dstage.flip()
+            self.prepare_decode(seqs)
+        n = len(seqs)
         self._next_rng(self.dstage)
         self.dstage.upload()
-        self._upload_done.record()
         bucket = next((b for b in self.graph_bs if b >= n), None) if self.graphs else None
         if bucket is not None:
             self.graphs[bucket].replay()
@@ -389,24 +424,27 @@ class ModelRunner:
             self._forward_decode(n)
         if self.world_size > 1:
             self._decode_tail(n)
+        host = self.tokens_host if self._flight_parity == 0 else self.tokens_host_b
+        done = self._step_done[self._flight_parity]
         if self.rank == 0:
-            self.tokens_host[:n].copy_(self.tokens_dev[:n], non_blocking=True)
-        self._inflight = n
+            host[:n].copy_(self.tokens_dev[:n], non_blocking=True)
+        done.record()
+        self._inflight.append((n, host, done))
+        self._flight_parity ^= 1
+        self._last_rows = {s.seq_id: i for i, s in enumerate(seqs)}
         return n
 
     def decode_end(self) -> list[int] | None:
-        """Wait for the step enqueued by `decode_begin` and return its sampled ids (rank 0)."""
-        n = self._inflight
-        self._inflight = 0
-        torch.cuda.current_stream().synchronize()
-        return self.tokens_host[:n].tolist() if self.rank == 0 else None
+        """Wait for the OLDEST step enqueued by `decode_begin` and return its sampled ids (rank 0)."""
+        n, host, done = self._inflight.pop(0)
+        done.synchronize()
+        return host[:n].tolist() if self.rank == 0 else None
 
     def stage_next_decode(self, seqs: list[Sequence]) -> None:
-        """Lookahead: fill the staging block for the NEXT decode step while the current one runs on the GPU
-        (everything but the input ids). The pinned block is free again once the current step's upload has
-        been consumed."""
-        self._upload_done.synchronize()
-        self.prepare_decode(seqs)
+        """Lookahead: fill the other pinned image for the NEXT decode step while the step just enqueued runs
+        (everything but the input ids, which the graph takes from that step's output on the device)."""
+        self.dstage.flip()
+        self.prepare_decode(seqs, self._last_rows)
 
     def _run_decode(self, seqs: list[Sequence]) -> list[int] | None:
         self.decode_begin(seqs)

@@ -47,6 +47,7 @@ SIGNATURES = {
     "nvl_sample_workspace_bytes": (c_size_t, [c_int64]),
     "nvl_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_void_p,
                            c_void_p, c_size_t, c_void_p]),
+    "nvl_feed_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "nvl_sample_exponentials_host": (None, [c_uint64, c_uint64, c_int64, c_int64, c_int64, c_void_p]),
 }
 
@@ -328,6 +329,14 @@ def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: 
                             offset_dev.data_ptr() if offset_dev is not None else None, workspace.data_ptr(),
                             workspace.numel() * workspace.element_size(), _stream()))
     return out
+
+
+def feed_tokens(ids: torch.Tensor, src_row: torch.Tensor, prev_tokens: torch.Tensor) -> None:
+    """ids[i] = prev_tokens[src_row[i]] where src_row[i] >= 0 (in place; int64 ids, int32 rows)."""
+    _dev(ids, "ids")
+    assert ids.dtype == torch.int64 and prev_tokens.dtype == torch.int64 and src_row.dtype == torch.int32
+    assert ids.is_contiguous() and src_row.is_contiguous() and src_row.numel() == ids.numel()
+    _check(lib().nvl_feed_tokens(ids.data_ptr(), src_row.data_ptr(), prev_tokens.data_ptr(), ids.numel(), _stream()))
 
 
 def sample_exponentials_host(seed: int, offset: int, row: int, col0: int, n: int):

@@ -41,7 +41,7 @@ def _run_ours(path, prompts, max_tokens, **kw):
             open_step.append(snap(*args))
         out = orig(method, *args)
         if method in ("run", "decode_end"):
-            step = open_step.pop()
+            step = open_step.pop(0)          # FIFO: with the lookahead, step N+1 begins before step N ends
             step["tokens"] = list(out)
             rec.append(step)
         return out
