@@ -473,6 +473,18 @@ def test_sampler_distribution(ops):
     assert chi2 < dof + 5 * math.sqrt(2 * dof), (chi2, dof)
 
 
+def test_feed_tokens(ops):
+    """nvl_feed_tokens: ids[i] = prev[src[i]] where src[i] >= 0, untouched elsewhere (bit-exact index work)."""
+    gen = g(50)
+    prev = torch.randint(0, 151936, (300,), generator=gen)
+    ids = torch.randint(0, 151936, (257,), generator=gen)
+    src = torch.randint(-1, 300, (257,), generator=gen).to(torch.int32)
+    want = torch.where(src >= 0, prev[src.clamp(min=0).long()], ids)
+    d_ids = dev(ids.clone())
+    ops.feed_tokens(d_ids, dev(src), dev(prev))
+    assert torch.equal(d_ids.cpu(), want)
+
+
 def test_errors_are_reported_not_thrown(ops):
     x = torch.zeros(4, 1000 + 4, dtype=BF16, device="cuda")  # hidden not a multiple of 8
     w = torch.zeros(1004, dtype=BF16, device="cuda")
