@@ -379,12 +379,13 @@ class ModelRunner:
         TP=1: layers + lm_head + sampler. TP>1: layers only (the logits gather to rank 0 and the
         sampler run eagerly in `_decode_tail`, as in the reference, model_runner.py:212,218).
 
-        Micro-batching (TP=1, bs >= 32): sequences are independent, so the batch is cut into two
-        half-batches whose layer chains are forked onto two HIP streams (two parallel branches of the
-        same captured hipGraph). A decode layer alternates one HBM-bound kernel (paged attention,
-        ~55 % of the step, VALU/launch path idle) with a dozen short latency-bound kernels (GEMMs at
-        M ~ 100, norms, rope) during which HBM idles; two chains out of phase fill each other's
-        gaps. Costs one extra pass over the weights per step (1.2 GB vs 13.5 GB of K/V)."""
+        Micro-batching (NVL_MICROBATCHES=2, off by default; TP=1, bs >= 32): sequences are independent, so
+        the batch can be cut into two half-batches whose layer chains are forked onto two HIP streams (two
+        parallel branches of the same captured hipGraph), hoping that one chain's HBM-bound attention overlaps
+        the other's short latency-bound kernels. Measured on MI355X / ROCm 7.2 the branches do not overlap
+        usefully (27-30 k vs 31.7 k tok/s) while every small kernel and one pass over the weights are paid
+        twice; kept as a tested option (tests/test_e2e_gpu.py) for stacks where graph branches do run
+        concurrently."""
         if self.microbatches > 1 and bs >= 32 and self.world_size == 1:
             h = bs // 2
             main = torch.cuda.current_stream()
