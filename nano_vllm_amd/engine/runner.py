@@ -363,8 +363,6 @@ class ModelRunner:
         t = self.dstage.t
         set_context(False, slot_mapping=t["slots"][r0:r1], context_lens=t["ctx"][r0:r1],
                     block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len)
-        # input ids of sequences that were in the previous decode step come straight from its sampled ids
-        ops.feed_tokens(t["ids"][r0:r1], t["src"][r0:r1], self.tokens_dev)
         hidden = self.model(t["ids"][r0:r1], t["pos"][r0:r1])
         if self.world_size == 1:
             logits = self.model.compute_logits(hidden)
@@ -386,6 +384,10 @@ class ModelRunner:
         usefully (27-30 k vs 31.7 k tok/s) while every small kernel and one pass over the weights are paid
         twice; kept as a tested option (tests/test_e2e_gpu.py) for stacks where graph branches do run
         concurrently."""
+        # input ids of sequences that were in the previous decode step come straight from its sampled ids
+        # (for the whole batch, BEFORE any chain of this step can overwrite tokens_dev)
+        t = self.dstage.t
+        ops.feed_tokens(t["ids"][:bs], t["src"][:bs], self.tokens_dev)
         if self.microbatches > 1 and bs >= 32 and self.world_size == 1:
             h = bs // 2
             main = torch.cuda.current_stream()

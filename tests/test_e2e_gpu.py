@@ -301,12 +301,16 @@ def test_lookahead_and_microbatch_modes_reproduce_the_serial_engine(tiny_ckpt, m
     compared at T=0.)"""
     from nano_vllm_amd import LLM, SamplingParams
     prompts = _prompts(40, 5, 300, 512, seed=31)
+    # ragged output lengths: sequences finish at different steps, so batch rows shift between steps and the
+    # device-side id feed (nvl_feed_tokens) has to follow them
+    lens = [3 + (7 * i) % 23 for i in range(40)]
 
     def run(temp, **env):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         llm = LLM(tiny_ckpt, enforce_eager=False, max_model_len=2048, num_kvcache_blocks=96, max_num_seqs=64, seed=7)
-        outs = llm.generate(prompts, SamplingParams(temperature=temp, max_tokens=10, ignore_eos=True), use_tqdm=False)
+        sps = [SamplingParams(temperature=temp, max_tokens=m, ignore_eos=True) for m in lens]
+        outs = llm.generate(prompts, sps, use_tqdm=False)
         llm.exit()
         for k in env:
             monkeypatch.delenv(k)
