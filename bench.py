@@ -39,26 +39,53 @@ REF_4070_LAPTOP_TOKS = 1434.13     # the reference's own number
 HBM_PEAK_GBPS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
+TP_MODELS = ("qwen3-32b", "qwen3-14b")     # models BASELINE.json quotes with tensor parallelism
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="qwen3-0.6b")
+    ap.add_argument("--tp", type=int, default=0,
+                    help="tensor_parallel_size of the engine; 0 = auto: --gpus for Qwen3-32B (BASELINE's second metric), "
+                         "1 otherwise (then --gpus N runs N data-parallel replicas)")
+    ap.add_argument("--workload", default="bench", choices=["bench", "prefix", "long"],
+                    help="bench = BASELINE config 2/4 (reference bench.py); prefix = config 3 (512-token shared system "
+                         "prompt x 256 seqs); long = config 5 (16 x 16,000-token prompts, 64 output tokens)")
     ap.add_argument("--num-seqs", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-tp-extra", action="store_true",
+                    help="with --gpus N > 1 on the default model: skip the additional Qwen3-32B TP=N measurement")
     ap.add_argument("--eager", action="store_true", help="enforce_eager=True (no hipGraph)")
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.9)
+    ap.add_argument("--num-kvcache-blocks", type=int, default=-1)
     return ap.parse_args()
 
 
-def workload(num_seqs: int):
-    """bench.py:9-18 of the reference, verbatim semantics."""
+def workload(num_seqs: int, kind: str = "bench"):
+    """bench: bench.py:9-18 of the reference, verbatim semantics. prefix / long: SURVEY.md §8(d) configs 3 / 5."""
     seed(0)
+    if kind == "prefix":
+        system = [randint(0, 10000) for _ in range(512)]
+        prompts = [system + [randint(0, 10000) for _ in range(randint(16, 256))] for _ in range(num_seqs)]
+        return prompts, [128] * num_seqs
+    if kind == "long":
+        n = min(num_seqs, 16)
+        return [[randint(0, 10000) for _ in range(16000)] for _ in range(n)], [64] * n
     prompts = [[randint(0, 10000) for _ in range(randint(100, 1024))] for _ in range(num_seqs)]
     outs = [randint(100, 1024) for _ in range(num_seqs)]
     return prompts, outs
+
+
+def engine_kwargs(args, tp: int) -> dict:
+    kw = dict(enforce_eager=args.eager, max_model_len=4096, dummy_weights=True, tensor_parallel_size=tp,
+              gpu_memory_utilization=args.gpu_memory_utilization, num_kvcache_blocks=args.num_kvcache_blocks)
+    if args.workload == "long":
+        kw.update(max_model_len=32768, max_num_batched_tokens=16384)
+    return kw
 
 
 def main():
@@ -66,13 +93,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # Functional check of the N>1 path on a 1-GPU box (not a measurement): NVL_BENCH_SHARE_GPU=1 puts every
+    tp = args.tp if args.tp > 0 else (max(args.gpus, world) if args.model in TP_MODELS else 1)
+    external_tp = world > 1 and tp == world            # torchrun started one process per GPU: they ARE the TP ranks
+    assert tp == 1 or world == 1 or external_tp, "--tp must be 1 or equal the number of launched ranks"
+    # Functional check of the N>1 paths on a 1-GPU box (not a measurement): NVL_BENCH_SHARE_GPU=1 puts every
     # rank on GPU 0 and NVL_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
     share_gpu = os.environ.get("NVL_BENCH_SHARE_GPU") == "1"
     backend = os.environ.get("NVL_BENCH_BACKEND", "nccl")
-    if world > 1 and not share_gpu:
-        # one replica per GPU: each process sees only its own device
+    if share_gpu:
+        os.environ.setdefault("NVL_TP_SHARE_GPU", "1")
+    if backend != "nccl":
+        os.environ.setdefault("NVL_TP_BACKEND", backend)
+    if world > 1 and not share_gpu and not external_tp and args.no_tp_extra:
+        # data-parallel replicas only: each process sees only its own device. (With the TP extra measurement, or
+        # in TP mode, every GPU stays visible and rank r selects device r, as the reference does.)
         os.environ["HIP_VISIBLE_DEVICES"] = str(local_rank)
+        local_rank = 0
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import torch
@@ -81,25 +117,153 @@ def main():
     from nano_vllm_amd import build as nvl_build
     if rank == 0 or world == 1:
         nvl_build.build()
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank,
-                                    device_id=torch.device("cuda", 0))
+                                    device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
         dist.barrier()
 
+    if external_tp:
+        result = run_tp_external(args, torch, dist, rank, world, tp)
+    else:
+        result = run_replica(args, torch, dist, rank, world, tp, backend)
+        if world > 1 and not args.no_tp_extra and args.model == "qwen3-0.6b" and args.workload == "bench":
+            extra = tp_extra(args, torch, dist, rank, world, result)
+            if rank == 0:
+                result["tp_qwen3_32b"] = extra
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def metric_name(args, tp: int) -> str:
+    shapes = {"qwen3-0.6b": "Qwen3-0.6B", "qwen3-8b": "Qwen3-8B", "qwen3-32b": "Qwen3-32B"}.get(args.model, args.model)
+    if args.workload == "bench":
+        return f"output tokens/s (bench.py, {args.num_seqs} seqs) {shapes} TP={tp}"
+    return f"output tokens/s ({args.workload} workload) {shapes} TP={tp}"
+
+
+def workload_note(args) -> str:
+    return {"bench": f"nano-vllm bench.py: {args.num_seqs} seqs, in/out U[100,1024], T=0.6, ignore_eos, max_model_len 4096",
+            "prefix": f"BASELINE config 3: 512-token shared system prompt + U[16,256] suffix x {args.num_seqs} seqs, 128 out, "
+                      "T=0.6, ignore_eos (prefix-cache path)",
+            "long": "BASELINE config 5: 16 x 16,000-token prompts, 64 out, max_model_len 32768, one prefill per step"
+            }[args.workload] + f", {args.model}"
+
+
+def timed_passes(args, torch, dist, llm, world, backend, rec=None, sync_group=True):
+    """reference bench.py:22-28: warm-up generate, then K timed passes bracketed by barrier + synchronize."""
+    from nanovllm import SamplingParams
+    prompts, out_lens = workload(args.num_seqs, args.workload)
+    sps = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=m) for m in out_lens]
+    llm.generate(["Benchmark: "], SamplingParams(), use_tqdm=False)          # reference bench.py:22
+    # Every pass starts COLD, like the reference's single timed generate(): without the reset, pass k+1 would
+    # serve the full 256-token blocks of the same prompts from the prefix cache pass k left behind. (The prefix
+    # workload keeps what it measures: sharing INSIDE a pass; the reset only removes sharing ACROSS passes.)
+    for _ in range(args.warmup):
+        llm.reset_prefix_cache()
+        llm.generate(prompts, sps, use_tqdm=False)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1 and sync_group:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if rec is not None:
+            rec["on"] = (k == args.steps - 1) and not args.no_roofline
+        llm.reset_prefix_cache()
+        llm.generate(prompts, sps, use_tqdm=False)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if rec is not None:
+        rec["on"] = False
+    return elapsed, prompts, out_lens
+
+
+def base_result(args, tp, world_engines, n_gpus, elapsed, total_out, llm, parallelism):
+    return {
+        "metric": metric_name(args, tp),
+        "value": total_out * args.steps * world_engines / elapsed,
+        "unit": "tok/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak" if tp == 1 else "strong",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": f"synthetic (seeded random weights, {args.model} shapes; token ids randint(0,10000) as reference bench.py)",
+        "config": {"workload": workload_note(args), "parallelism": parallelism,
+                   "hipgraph": not llm.model_runner.enforce_eager, "kv_blocks": llm.config.num_kvcache_blocks,
+                   "output_tokens_per_step": total_out},
+    }
+
+
+def run_tp_external(args, torch, dist, rank, world, tp):
+    """One engine, tensor-parallel over the `world` ranks torchrun started (BASELINE: Qwen3-32B TP=N): rank 0
+    hosts the scheduler and posts steps, the other ranks execute them (LLMEngine.worker)."""
     from nano_vllm_amd.weights import write_synthetic_checkpoint
-    from nanovllm import LLM, SamplingParams
+    from nanovllm import LLM
+    path = os.path.join(tempfile.gettempdir(), f"nvl_{args.model}_r{rank}")
+    write_synthetic_checkpoint(path, args.model, with_weights=False)
+    kw = engine_kwargs(args, tp)
+    if rank > 0:
+        LLM.worker(path, **kw)             # returns when rank 0 exits the engine
+        return None
+    llm = LLM(path, **kw)
+    elapsed, prompts, out_lens = timed_passes(args, torch, dist, llm, world, "nccl", sync_group=False)
+    total_out = sum(out_lens)
+    result = base_result(args, tp, 1, world, elapsed, total_out, llm,
+                         f"tp{tp} (one engine, tensor-parallel over {tp} GPUs: xGMI P2P all-reduce "
+                         f"{'on' if llm.model_runner.p2p else 'OFF (process-group fallback)'})")
+    llm.exit()
+    return result
+
+
+def tp_extra(args, torch, dist, rank, world, primary) -> dict | None:
+    """BASELINE's second metric next to the data-parallel line of a multi-GPU run: Qwen3-32B with
+    tensor_parallel_size = world, one cold pass. Guarded: whatever happens here, the primary line is printed."""
+    import copy
+    import threading
+    a = copy.copy(args)
+    a.model, a.steps, a.warmup, a.no_roofline, a.no_cpu_baseline = "qwen3-32b", 1, 0, True, True
+    if rank == 0:
+        def bail():
+            primary["tp_qwen3_32b"] = {"error": "timed out"}
+            print(json.dumps(primary), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(float(os.environ.get("NVL_BENCH_TP_EXTRA_TIMEOUT", "900")), bail)
+        watchdog.daemon = True
+        watchdog.start()
+    try:
+        r = run_tp_external(a, torch, dist, rank, world, world)
+    except Exception as ex:  # noqa: BLE001 — a secondary measurement must never sink the bench line
+        r = {"error": repr(ex)}
+    if rank == 0:
+        watchdog.cancel()
+    return r
+
+
+def run_replica(args, torch, dist, rank, world, tp, backend):
+    """One engine per launched process (TP = 1: N independent data-parallel replicas; or, launched as a single
+    process with --tp T, one engine that spawns its own T - 1 workers)."""
+    from nano_vllm_amd.weights import write_synthetic_checkpoint
+    from nanovllm import LLM
 
     path = os.path.join(tempfile.gettempdir(), f"nvl_{args.model}_r{rank}")
     write_synthetic_checkpoint(path, args.model, with_weights=False)
-    llm = LLM(path, enforce_eager=args.eager, max_model_len=4096, dummy_weights=True,
-              gpu_memory_utilization=args.gpu_memory_utilization)
-
-    prompts, out_lens = workload(args.num_seqs)
-    sps = [SamplingParams(temperature=0.6, ignore_eos=True, max_tokens=m) for m in out_lens]
-    total_out = sum(out_lens)
+    llm = LLM(path, **engine_kwargs(args, tp))
 
     # ---- record decode batches of a pass (for the roofline replay) --------------------------
     runner = llm.model_runner
@@ -130,7 +294,7 @@ def main():
 
     # ---- host-side time of the timed pass. With the decode lookahead (engine/core.py) schedule, postprocess
     #      and prepare_decode of step N+1 run while the GPU executes step N; only fill_tokens is serial. -----
-    host = {"schedule_s": 0.0, "postprocess_s": 0.0, "prepare_decode_s": 0.0}
+    host = {"schedule_s": 0.0, "postprocess_s": 0.0, "prepare_decode_s": 0.0, "prefill_steps_s": 0.0}
 
     def timed(fn, key):
         def wrapper(*a, **kw):
@@ -146,60 +310,28 @@ def main():
     llm.scheduler.postprocess = timed(llm.scheduler.postprocess, "postprocess_s")     # (postprocess_early calls it)
     llm.scheduler.fill_tokens = timed(llm.scheduler.fill_tokens, "postprocess_s")
     runner.prepare_decode = timed(runner.prepare_decode, "prepare_decode_s")
+    # a prefill step starts on a drained queue and ends with a stream sync: its host wall time is its GPU time
+    runner._run_prefill = timed(runner._run_prefill, "prefill_steps_s")
 
-    llm.generate(["Benchmark: "], SamplingParams(), use_tqdm=False)          # reference bench.py:22
-    # Every pass starts COLD, like the reference's single timed generate(): without the reset, pass k+1 would
-    # serve the full 256-token blocks of the same prompts from the prefix cache pass k left behind.
-    for _ in range(args.warmup):
-        llm.reset_prefix_cache()
-        llm.generate(prompts, sps, use_tqdm=False)
-
-    def sync_all():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    sync_all()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        rec["on"] = (k == args.steps - 1) and not args.no_roofline
-        llm.reset_prefix_cache()
-        llm.generate(prompts, sps, use_tqdm=False)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    rec["on"] = False
+    elapsed, prompts, out_lens = timed_passes(args, torch, dist, llm, world, backend, rec)
+    total_out = sum(out_lens)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    result = {
-        "metric": "output tokens/s (bench.py, 256 seqs) Qwen3-0.6B TP=1" if args.model == "qwen3-0.6b" else
-                  f"output tokens/s (bench.py, {args.num_seqs} seqs) {args.model} TP=1",
-        "value": total_out * args.steps * world / elapsed,
-        "unit": "tok/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
-        "dtype": "bf16",
-        "data": f"synthetic (seeded random weights, {args.model} shapes; token ids randint(0,10000) as reference bench.py)",
-        "config": {"workload": f"nano-vllm bench.py: {args.num_seqs} seqs, in/out U[100,1024], T=0.6, ignore_eos, "
-                               f"max_model_len 4096, {args.model}", "parallelism": f"dp{world} (1 engine replica per GPU, TP=1)",
-                   "hipgraph": not args.eager, "kv_blocks": llm.config.num_kvcache_blocks,
-                   "output_tokens_per_step": total_out},
-    }
-    if args.num_seqs == 256 and args.model == "qwen3-0.6b":
+    par = (f"dp{world} (1 engine replica per GPU, TP=1)" if tp == 1 else
+           f"tp{tp} (one engine, {tp} ranks spawned by the engine; xGMI P2P all-reduce "
+           f"{'on' if runner.p2p else 'OFF (process-group fallback)'})")
+    result = base_result(args, tp, world, world * (tp if world == 1 else 1), elapsed, total_out, llm, par)
+    if args.num_seqs == 256 and args.model == "qwen3-0.6b" and args.workload == "bench" and tp == 1:
         result["vs_baseline"] = result["value"] / REF_4070_LAPTOP_TOKS
         result["config"]["baseline_note"] = "vs_baseline = value / 1434.13 tok/s (reference README, RTX 4070 Laptop: other hardware)"
 
-    if rank == 0 and not args.no_roofline and rec["samples"]:
+    if rank == 0 and not args.no_roofline and rec["samples"] and tp == 1:
         result["config"]["host_seconds_in_last_step"] = {k: round(v, 4) for k, v in host.items()}
-        result["roofline"] = roofline_replay(torch, runner, rec)
+        result["roofline"] = roofline_replay(torch, runner, rec, args.model)
+        result["roofline"]["decode_step"] = decode_step_roofline(runner, rec, result, host["prefill_steps_s"])
         if rec.get("prefill"):
             result["roofline_prefill"] = prefill_replay(torch, runner, rec["prefill"])
     if rank == 0 and not args.no_cpu_baseline:
@@ -207,15 +339,30 @@ def main():
             result["cpu_baseline"] = cpu_baseline(torch, llm, args.model, prompts, out_lens)
         except Exception as ex:  # noqa: BLE001 — a reported baseline must never sink the bench line
             result["cpu_baseline"] = {"error": repr(ex)}
-    if rank == 0:
-        print(json.dumps(result), flush=True)
     llm.exit()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    return result
 
 
-def roofline_replay(torch, runner, rec) -> dict:
+def decode_step_roofline(runner, rec, result, prefill_s: float) -> dict:
+    """The whole decode STEP against the HBM roofline (not just its dominant kernel): algorithmic bytes of the
+    pass's decode steps (every weight once per step + K/V of every context token) over the time of
+    the last pass minus its prefill steps (host-timed: a prefill starts on a drained queue and ends in a sync)."""
+    geo = runner.geo
+    L, hkv = geo["layers"], geo["kv_heads"]
+    kv_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * 2 * L
+    # streamed once per step: every layer + the lm_head matrix (the tied embedding table when tie_word_embeddings);
+    # the embedding GATHER touches only one row per sequence
+    params = sum(p.numel() for n, p in runner.model.named_parameters()
+                 if not (n.startswith("lm_head") and geo["tie"]) and not ("embed_tokens" in n and not geo["tie"]))
+    w_bytes = params * 2 * rec["steps"]
+    sec = result["ms_per_step"] * 1e-3 - prefill_s
+    gbps = (kv_bytes + w_bytes) / sec / 1e9
+    return {"algorithmic_bytes": kv_bytes + w_bytes, "decode_seconds": sec, "prefill_seconds": prefill_s,
+            "decode_steps": rec["steps"], "achieved_GBps": gbps, "frac_of_8TBps": gbps / HBM_PEAK_GBPS,
+            "note": "pass time (mean over the timed passes) minus the prefill steps of the last pass"}
+
+
+def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
     """Time the decode-attention kernel alone on the recorded batches (HIP events on the launch
     stream, every layer's cache => cold K/V like in the real step). Same code path as
     tools/attn_replay.py, which is the command the rocprofv3 duration/PMC profiles are taken with."""
@@ -226,7 +373,7 @@ def roofline_replay(torch, runner, rec) -> dict:
     achieved = r["achieved_GBps"]
     step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * 2 * L
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"]),
+            "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"], model),
             "kernel": (f"decode_stream_kernel<{hq // hkv}, fused>" if hq // hkv != 8 else "decode_mfma8_kernel<fused>")
                       + " + decode_stream_combine_kernel (nvl_paged_attn_decode_fused: the launch the decode step makes)",
             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],
@@ -268,16 +415,19 @@ def prefill_replay(torch, runner, batches) -> dict:
             "note": "prefill batches of the timed pass (up to 16,384 tokens of 100-1024-token prompts per launch)"}
 
 
-def pmc_traffic(alg_bytes_per_launch: float):
-    """HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/pmc_traffic.json:
-    FETCH_SIZE summed over the decode_stream_kernel launches of tools/attn_replay.py, doubled as
-    MI355X_MICROARCH.md §HBM prescribes for 16 B/lane streaming reads on gfx950, divided by the
-    algorithmic bytes of the same launches). PMC counters cannot be read from inside this process,
-    so the ratio measured by that separate pass is applied to this run's bytes per launch; null
-    when no PMC pass has been recorded."""
+def pmc_traffic(alg_bytes_per_launch: float, model: str = "qwen3-0.6b"):
+    """HBM bytes per launch from the committed rocprofv3 PMC pass of THIS model's decode-attention launches
+    (profiles/pmc_traffic.json: FETCH_SIZE summed over the decode_stream_kernel launches of
+    tools/attn_replay.py, doubled as MI355X_MICROARCH.md §HBM prescribes for 16 B/lane streaming reads on
+    gfx950, divided by the algorithmic bytes of the same launches). PMC counters cannot be read from inside
+    this process, so the ratio measured by that separate pass is applied to this run's bytes per launch — it is
+    a property of the kernel's access pattern, not of the run. null when no PMC pass exists for the model."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
-            ratio = float(json.load(fh)["hbm_read_bytes_over_algorithmic"])
+            rec = json.load(fh)
+        if rec.get("model", "qwen3-0.6b") != model:
+            return None
+        ratio = float(rec["hbm_read_bytes_over_algorithmic"])
     except (OSError, KeyError, ValueError):
         return None
     return ratio * alg_bytes_per_launch

@@ -17,7 +17,8 @@
  *     layers/attention.py:28).
  *   - enqueue-only on `stream`: no allocation, no synchronisation, no host
  *     callbacks => every call is hipGraph-capturable. The caller owns all
- *     buffers including workspaces.
+ *     buffers including workspaces. (Exceptions, init-time only:
+ *     nvl_allreduce_create / _connect / _status / _destroy.)
  *   - return 0 on success, negative NVL_E* on error (arguments are validated
  *     on the host before anything is launched); nvl_last_error() returns a
  *     thread-local message. Nothing throws across the ABI.
@@ -245,6 +246,24 @@ int nvl_sample(const void* logits, int64_t logits_row_stride,
                uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                void* workspace, size_t workspace_bytes, void* stream);
 
+/* Vocab-parallel form of the sampler (the reference gathers every rank's [batch, vocab/tp]
+ * logits on rank 0, layers/embed_head.py:62-65, and samples there; here each rank reduces ITS
+ * shard to one {key, index} pair per row and only those 8 bytes per row travel):
+ *   nvl_sample_shard : logits = this rank's [batch, vocab_local] slice whose column 0 is global
+ *                      vocabulary index col_offset (multiple of 8). Same Philox stream as
+ *                      nvl_sample over the full row (keyed by GLOBAL column), so merging the
+ *                      shards' winners reproduces nvl_sample on the concatenated logits exactly.
+ *                      best_packed: [batch][2] 32-bit words {float key bits, global index}.
+ *   nvl_sample_merge : best_packed = `parts` such arrays, part_stride_bytes apart; out[b] =
+ *                      index of the largest key (lowest index on ties), int64. */
+int nvl_sample_shard(const void* logits, int64_t logits_row_stride,
+                     const float* temperatures, void* best_packed,
+                     int64_t batch, int64_t vocab_local, int64_t col_offset,
+                     uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int nvl_sample_merge(const void* best_packed, int parts, int64_t part_stride_bytes,
+                     int64_t* out, int64_t batch, void* stream);
+
 /* Feed the previous step's sampled ids back as this step's input ids ON THE DEVICE:
  *   ids[i] = src_row[i] >= 0 ? prev_tokens[src_row[i]] : ids[i]
  * The reference round-trips every sampled id through the host (`.tolist()` at
@@ -254,6 +273,37 @@ int nvl_sample(const void* logits, int64_t logits_row_stride,
  * (row of the sequence in the previous decode batch, -1 = take the staged id). */
 int nvl_feed_tokens(int64_t* ids, const int32_t* src_row, const int64_t* prev_tokens,
                     int64_t n, void* stream);
+
+/* ---- Tensor-parallel collectives over xGMI (decode-sized messages) -----------------------
+ * Replace dist.all_reduce after the row-parallel GEMMs (layers/linear.py:153-156) and after
+ * the vocab-parallel embedding (layers/embed_head.py:41), and dist.gather of the logits
+ * (layers/embed_head.py:62-65), which the reference sends through NCCL. One process per GPU;
+ * every rank's comm buffer is mapped into every process with hipIpc and the kernels read the
+ * peers directly over the fully connected xGMI links (csrc/comm.hip describes the protocol).
+ *   create  : allocates this rank's buffer (the ONLY allocation; sized for max_bytes per call)
+ *   uid     : 64-byte token (IPC memory handle) the peers need; exchange them out of band
+ *   connect : uids = world x 64 bytes, rank order; maps the peers. A host-side barrier across
+ *             ranks must separate connect from the first collective.
+ *   run / add_rmsnorm / gather : enqueue-only on `stream`, hipGraph-capturable, results
+ *             identical on every rank and run to run (fixed summation order, one bf16 rounding):
+ *             run          out[rows, hidden] = sum over ranks of in (bf16; out may alias in)
+ *             add_rmsnorm  the all-reduce fused with RMSNorm.add_rms_forward
+ *                          (layers/layernorm.py:28-40): s = bf16(sum_r x_partial) + residual;
+ *                          residual <- bf16(s); y = bf16(s * rsqrt(mean s^2 + eps) * w)
+ *             gather       out[world][bytes_per_rank] = every rank's `in` (<= 4 KiB each)
+ *             Every rank must issue the same sequence of calls with the same shapes.
+ *   status  : NVL_OK, or NVL_ELAUNCH if a kernel gave up waiting for a peer (spins are bounded;
+ *             synchronises the device — not for use inside a capture). */
+int nvl_allreduce_create(int rank, int world, int64_t max_bytes, void** comm_out);
+int nvl_allreduce_uid(void* comm, void* uid_out_64B);
+int nvl_allreduce_connect(void* comm, const void* uids);
+int64_t nvl_allreduce_max_bytes(void* comm);
+int nvl_allreduce_run(void* comm, const void* in, void* out, int64_t rows, int hidden, void* stream);
+int nvl_allreduce_add_rmsnorm(void* comm, const void* x_partial, void* residual, const void* weight,
+                              void* y, int64_t rows, int hidden, float eps, void* stream);
+int nvl_allreduce_gather(void* comm, const void* in, void* out, int64_t bytes_per_rank, void* stream);
+int nvl_allreduce_status(void* comm);
+int nvl_allreduce_destroy(void* comm);
 
 /* Host-side reference of the sampler's RNG (same Philox stream as the
  * kernel): fills e[n] with the Exp(1) draws for columns [col0, col0+n) of

@@ -38,7 +38,7 @@ __device__ __forceinline__ Best better(Best a, Best b) {
 
 __global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __restrict__ logits, int64_t row_stride,
                                                               const float* __restrict__ temps, int64_t vocab,
-                                                              uint64_t seed, uint64_t offset,
+                                                              int64_t col_offset, uint64_t seed, uint64_t offset,
                                                               const uint64_t* __restrict__ offset_dev,
                                                               float* __restrict__ ws_val, int* __restrict__ ws_idx) {
   __shared__ float sv[4];
@@ -57,8 +57,12 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __res
   const int64_t c_end = min(nchunks, c_begin + per);
   Best best{-INFINITY, 0x7fffffff};
   const bool vec_ok = ((reinterpret_cast<uintptr_t>(lr) & 15) == 0);
+  // `col_offset` (a multiple of 8) = global vocabulary index of local column 0: a vocab-parallel shard
+  // (embed_head.py:56-66) draws the SAME exponentials and reports the SAME indices as the full row would.
+  const int64_t gchunk0 = col_offset >> 3;
   for (int64_t c = c_begin + threadIdx.x; c < c_end; c += 256) {
     const int64_t col0 = c * 8;
+    const int64_t gc = c + gchunk0;
     float f[8];
     if (vec_ok && col0 + 8 <= vocab) {
       unpack8(*reinterpret_cast<const u32x4_t*>(lr + col0), f);
@@ -71,9 +75,9 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __res
 #pragma unroll
       for (int i = 0; i < 8; ++i) key[i] = f[i];
     } else {
-      const Philox4 r0 = philox4x32_10((uint32_t)(2 * c), (uint32_t)((2 * c) >> 32) ^ (uint32_t)(off << 8), (uint32_t)row,
+      const Philox4 r0 = philox4x32_10((uint32_t)(2 * gc), (uint32_t)((2 * gc) >> 32) ^ (uint32_t)(off << 8), (uint32_t)row,
                                        (uint32_t)(off >> 24), k0, k1);
-      const Philox4 r1 = philox4x32_10((uint32_t)(2 * c + 1), (uint32_t)((2 * c + 1) >> 32) ^ (uint32_t)(off << 8),
+      const Philox4 r1 = philox4x32_10((uint32_t)(2 * gc + 1), (uint32_t)((2 * gc + 1) >> 32) ^ (uint32_t)(off << 8),
                                        (uint32_t)row, (uint32_t)(off >> 24), k0, k1);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __res
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      if (col0 + i < vocab) best = better(best, Best{key[i], (int)(col0 + i)});
+      if (col0 + i < vocab) best = better(best, Best{key[i], (int)(col_offset + col0 + i)});
     }
   }
 #pragma unroll
@@ -106,14 +110,39 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __res
   }
 }
 
-__global__ __launch_bounds__(64) void sample_final_kernel(const float* __restrict__ ws_val,
-                                                           const int* __restrict__ ws_idx, int64_t* __restrict__ out,
+// Merge `parts` (value, index) partials per row: part p of row r lives at val[p * part_stride + r * inner + j],
+// j < inner (inner = kSplits for the workgroup partials of one launch, 1 for per-rank results). Either writes the
+// winning index (int64, what Sampler.forward returns) or the packed {value bits, index} pair of a shard.
+__global__ __launch_bounds__(64) void sample_merge_kernel(const float* __restrict__ val, const int* __restrict__ idx,
+                                                           int parts, int64_t part_stride, int inner,
+                                                           int64_t* __restrict__ out, uint32_t* __restrict__ out_packed,
                                                            int64_t batch) {
   const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (row >= batch) return;
-  Best b{ws_val[row * kSplits], ws_idx[row * kSplits]};
-#pragma unroll
-  for (int s = 1; s < kSplits; ++s) b = better(b, Best{ws_val[row * kSplits + s], ws_idx[row * kSplits + s]});
+  Best b{-INFINITY, 0x7fffffff};
+  for (int p = 0; p < parts; ++p)
+    for (int j = 0; j < inner; ++j) {
+      const int64_t at = p * part_stride + row * inner + j;
+      b = better(b, Best{val[at], idx[at]});
+    }
+  if (out) out[row] = b.idx == 0x7fffffff ? 0 : (int64_t)b.idx;
+  if (out_packed) {
+    out_packed[row * 2] = __float_as_uint(b.v);
+    out_packed[row * 2 + 1] = (uint32_t)b.idx;
+  }
+}
+
+// packed {value bits, index} pairs [parts][batch][2] (one part per tensor-parallel rank) -> winning index
+__global__ __launch_bounds__(64) void sample_merge_packed_kernel(const uint32_t* __restrict__ packed, int parts,
+                                                                  int64_t part_stride_words, int64_t* __restrict__ out,
+                                                                  int64_t batch) {
+  const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (row >= batch) return;
+  Best b{-INFINITY, 0x7fffffff};
+  for (int p = 0; p < parts; ++p) {
+    const uint32_t* q = packed + p * part_stride_words + row * 2;
+    b = better(b, Best{__uint_as_float(q[0]), (int)q[1]});
+  }
   out[row] = b.idx == 0x7fffffff ? 0 : (int64_t)b.idx;
 }
 
@@ -124,24 +153,57 @@ extern "C" size_t nvl_sample_workspace_bytes(int64_t max_batch) {
   return (size_t)max_batch * kSplits * (sizeof(float) + sizeof(int));
 }
 
-extern "C" int nvl_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, int64_t* out,
-                          int64_t batch, int64_t vocab, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                          void* workspace, size_t workspace_bytes, void* stream) {
-  NVL_REQUIRE(logits && temperatures && out && workspace, "nvl_sample: null pointer");
-  NVL_REQUIRE(batch >= 0 && batch <= 65535, "nvl_sample: batch=%lld out of range [0, 65535]", (long long)batch);
-  NVL_REQUIRE(vocab > 0 && vocab < (1ll << 31) - 8, "nvl_sample: bad vocab=%lld", (long long)vocab);
-  NVL_REQUIRE(logits_row_stride >= vocab, "nvl_sample: row stride < vocab");
-  NVL_REQUIRE(workspace_bytes >= nvl_sample_workspace_bytes(batch), "nvl_sample: workspace too small");
-  NVL_REQUIRE(((uintptr_t)workspace) % 8 == 0, "nvl_sample: workspace must be 8-byte aligned");
+namespace {
+int sample_common(const void* logits, int64_t logits_row_stride, const float* temperatures, int64_t* out,
+                  uint32_t* out_packed, int64_t batch, int64_t vocab, int64_t col_offset, uint64_t seed, uint64_t offset,
+                  const uint64_t* offset_dev, void* workspace, size_t workspace_bytes, void* stream, const char* who) {
+  NVL_REQUIRE(logits && temperatures && (out || out_packed) && workspace, "%s: null pointer", who);
+  NVL_REQUIRE(batch >= 0 && batch <= 65535, "%s: batch=%lld out of range [0, 65535]", who, (long long)batch);
+  NVL_REQUIRE(vocab > 0 && col_offset >= 0 && col_offset + vocab < (1ll << 31) - 8, "%s: bad vocab=%lld (+%lld)", who,
+              (long long)vocab, (long long)col_offset);
+  NVL_REQUIRE(col_offset % 8 == 0, "%s: col_offset=%lld must be a multiple of 8", who, (long long)col_offset);
+  NVL_REQUIRE(logits_row_stride >= vocab, "%s: row stride < vocab", who);
+  NVL_REQUIRE(workspace_bytes >= nvl_sample_workspace_bytes(batch), "%s: workspace too small", who);
+  NVL_REQUIRE(((uintptr_t)workspace) % 8 == 0, "%s: workspace must be 8-byte aligned", who);
   if (batch == 0) return NVL_OK;
   float* ws_val = (float*)workspace;
   int* ws_idx = (int*)(ws_val + (size_t)batch * kSplits);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(sample_partial_kernel, dim3(kSplits, (unsigned)batch), dim3(256), 0, s, (const bf16_t*)logits,
-                     logits_row_stride, temperatures, vocab, seed, offset, offset_dev, ws_val, ws_idx);
-  hipLaunchKernelGGL(sample_final_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, ws_val, ws_idx, out,
-                     batch);
-  return nvl_check_launch("nvl_sample");
+                     logits_row_stride, temperatures, vocab, col_offset, seed, offset, offset_dev, ws_val, ws_idx);
+  hipLaunchKernelGGL(sample_merge_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, ws_val, ws_idx, 1,
+                     (int64_t)0, kSplits, out, out_packed, batch);
+  return nvl_check_launch(who);
+}
+}  // namespace
+
+extern "C" int nvl_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, int64_t* out,
+                          int64_t batch, int64_t vocab, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                          void* workspace, size_t workspace_bytes, void* stream) {
+  return sample_common(logits, logits_row_stride, temperatures, out, nullptr, batch, vocab, 0, seed, offset,
+                       offset_dev, workspace, workspace_bytes, stream, "nvl_sample");
+}
+
+extern "C" int nvl_sample_shard(const void* logits, int64_t logits_row_stride, const float* temperatures,
+                                void* best_packed, int64_t batch, int64_t vocab_local, int64_t col_offset,
+                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* workspace,
+                                size_t workspace_bytes, void* stream) {
+  NVL_REQUIRE(((uintptr_t)best_packed) % 8 == 0, "nvl_sample_shard: best_packed must be 8-byte aligned");
+  return sample_common(logits, logits_row_stride, temperatures, nullptr, (uint32_t*)best_packed, batch, vocab_local,
+                       col_offset, seed, offset, offset_dev, workspace, workspace_bytes, stream, "nvl_sample_shard");
+}
+
+extern "C" int nvl_sample_merge(const void* best_packed, int parts, int64_t part_stride_bytes, int64_t* out,
+                                int64_t batch, void* stream) {
+  NVL_REQUIRE(best_packed && out, "nvl_sample_merge: null pointer");
+  NVL_REQUIRE(parts >= 1 && parts <= 1024, "nvl_sample_merge: parts=%d out of range", parts);
+  NVL_REQUIRE(batch >= 0 && batch <= 65535, "nvl_sample_merge: batch=%lld out of range", (long long)batch);
+  NVL_REQUIRE(part_stride_bytes % 8 == 0 && part_stride_bytes >= batch * 8, "nvl_sample_merge: bad part stride");
+  NVL_REQUIRE(((uintptr_t)best_packed) % 8 == 0, "nvl_sample_merge: best_packed must be 8-byte aligned");
+  if (batch == 0) return NVL_OK;
+  hipLaunchKernelGGL(sample_merge_packed_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                     (const uint32_t*)best_packed, parts, part_stride_bytes / 4, out, batch);
+  return nvl_check_launch("nvl_sample_merge");
 }
 
 namespace {

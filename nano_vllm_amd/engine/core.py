@@ -17,9 +17,15 @@ from .sched import Scheduler
 from .seq import Sequence
 
 
-def _worker_main(config, rank, event):
+def _worker_main(config, rank, env):
+    os.environ.update(env)                 # NVL_TP_* switches of the parent (spawn does not copy later changes)
     from .runner import ModelRunner
-    ModelRunner(config, rank, event)       # never returns until "exit" (runner.loop)
+    ModelRunner(config, rank)              # never returns until "exit" (runner.loop)
+
+
+def _external_tp_group(size: int) -> bool:
+    import torch.distributed as dist
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() == size
 
 
 class LLMEngine:
@@ -29,28 +35,44 @@ class LLMEngine:
         config = Config(model, **{k: v for k, v in kwargs.items() if k in known})
         self.config = config
         Sequence.block_size = config.kvcache_block_size
-        self.ps, self.events = [], []
-        if config.tensor_parallel_size > 1:
+        self.ps = []
+        if config.tensor_parallel_size > 1 and not _external_tp_group(config.tensor_parallel_size):
+            # one process per GPU, spawned here (llm_engine.py:24-30). When the caller already runs one process
+            # per GPU under torch.distributed (torchrun: bench.py --tp N), ranks > 0 call `LLMEngine.worker`
+            # instead and nothing is spawned.
             import torch.multiprocessing as mp
             ctx = mp.get_context("spawn")
+            env = {k: v for k, v in os.environ.items() if k.startswith("NVL_")}
             for rank in range(1, config.tensor_parallel_size):
-                event = ctx.Event()
-                proc = ctx.Process(target=_worker_main, args=(config, rank, event))
+                proc = ctx.Process(target=_worker_main, args=(config, rank, env))
                 proc.start()
                 self.ps.append(proc)
-                self.events.append(event)
         from .runner import ModelRunner
-        self.model_runner = ModelRunner(config, 0, self.events)     # also fills config.num_kvcache_blocks
+        self.model_runner = ModelRunner(config, 0)                  # also fills config.num_kvcache_blocks
         from transformers import AutoTokenizer
         self.tokenizer = AutoTokenizer.from_pretrained(config.model, use_fast=True)
         config.eos = self.tokenizer.eos_token_id if self.tokenizer.eos_token_id is not None else -1
         self.scheduler = Scheduler(config)
-        # decode lookahead (see _step_lookahead): TP = 1 only (workers would need the split protocol);
-        # NVL_LOOKAHEAD=0 restores the strictly serial loop for A/B measurements
-        self._lookahead = config.tensor_parallel_size == 1 and os.environ.get("NVL_LOOKAHEAD", "1") != "0"
+        # decode lookahead (see _step_lookahead), at any TP degree: workers execute the staging images rank 0
+        # posts, and every rank holds the sampled ids on the device. NVL_LOOKAHEAD=0 restores the strictly
+        # serial loop for A/B measurements
+        self._lookahead = os.environ.get("NVL_LOOKAHEAD", "1") != "0"
         self._unfilled = None              # sequences of an in-flight lookahead step whose token values are pending
         self._exited = False
         atexit.register(self.exit)
+
+    @classmethod
+    def worker(cls, model, **kwargs) -> None:
+        """Tensor-parallel worker entry point for externally launched ranks (torchrun): call it with the SAME
+        arguments rank 0 passes to `LLM(...)` from every process whose torch.distributed rank is > 0. Returns
+        when rank 0's engine exits."""
+        import torch.distributed as dist
+        known = {f.name for f in fields(Config)}
+        config = Config(model, **{k: v for k, v in kwargs.items() if k in known})
+        assert dist.is_initialized() and dist.get_world_size() == config.tensor_parallel_size and dist.get_rank() > 0
+        Sequence.block_size = config.kvcache_block_size
+        from .runner import ModelRunner
+        ModelRunner(config, dist.get_rank())
 
     def exit(self):
         if self._exited:
@@ -65,6 +87,11 @@ class LLMEngine:
         if isinstance(prompt, str):
             prompt = self.tokenizer.encode(prompt)
         assert len(prompt) > 0, "empty prompt"
+        # the staging block tables and the RoPE table are sized by max_model_len: a request that would outgrow
+        # them is refused here instead of failing mid-generation
+        assert len(prompt) + sampling_params.max_tokens <= self.config.max_model_len, (
+            f"prompt ({len(prompt)} tokens) + max_tokens ({sampling_params.max_tokens}) exceeds "
+            f"max_model_len ({self.config.max_model_len})")
         self.scheduler.add(Sequence(prompt, sampling_params))
 
     def step(self):

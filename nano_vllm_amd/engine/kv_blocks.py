@@ -4,7 +4,8 @@ Same observable behaviour as the reference's `BlockManager` (nano-vllm
 engine/block_manager.py:26-120): identical allocation ORDER (FIFO free list), identical hash
 chain (xxh64 over an 8-byte LE prefix hash + the block's int64 token bytes, :35-41), identical
 reuse / revival / eviction rules — verified against the imported reference on random traces in
-tests/test_host_logic_vs_reference.py. What differs is the data structure, sized for the
+tests/test_host_logic.py (golden traces recorded from the imported reference) and
+tests/test_oracle_vs_reference.py. What differs is the data structure, sized for the
 ~10^4-10^5 blocks that 288 GB of HBM gives one MI355X:
   * no per-block Python object: ref counts / hashes / token fingerprints live in flat lists;
   * the free list is an intrusive doubly-linked list over block ids, so reviving a cached block
@@ -38,6 +39,7 @@ class BlockManager:
         self._in_free = [True] * num_blocks
         self.num_free = num_blocks
         self._probe: tuple | None = None
+        self._table_gen = 0           # allocation counter: every allocate() stamps the sequence (see allocate)
 
     # --- hashing (block_manager.py:35-41) -----------------------------------------------------
     @staticmethod
@@ -145,6 +147,10 @@ class BlockManager:
         for _ in range(num_cached_blocks, seq.num_blocks):
             table.append(self._allocate_block())
         seq.num_cached_tokens = num_cached_blocks * self.block_size
+        # A preempted sequence that is allocated again can come back with the same NUMBER of blocks but other
+        # block ids; anything that caches per-sequence table rows (engine/runner.py) keys them by this stamp.
+        self._table_gen += 1
+        seq.table_gen = self._table_gen
 
     def deallocate(self, seq: Sequence) -> None:
         """Free in reverse so a sequence's prefix blocks are recycled last (:94-101)."""

@@ -17,11 +17,17 @@ spec in SURVEY.md Appendix A.3), re-designed around the MI355X host/device bound
     bucket at TP=1 (the reference captures the layers only and runs lm_head + sampler eagerly).
   * KV cache layout [L, 2, num_blocks, Hkv, block, 128] (layer-major, head-major blocks), zero-initialised;
     sized by the reference's formula (model_runner.py:103-115).
+  * Tensor parallelism (model_runner.py:26,41-89): rank 0 prepares a step ONCE and ships the filled staging
+    image — a fixed binary layout, not pickled Sequence objects — to the workers through a ring of slots in
+    POSIX shared memory (`_Channel`); workers copy it into their own pinned block, upload and launch. Every
+    rank samples its vocabulary shard and the 8-byte-per-row winners are exchanged over xGMI, so every rank
+    holds the sampled ids on the device and the decode lookahead works unchanged at TP > 1.
 """
 from __future__ import annotations
 
 import os
 import pickle
+import time
 
 import numpy as np
 import torch
@@ -36,7 +42,106 @@ from ..weights import init_dummy_weights, load_model
 from .seq import Sequence
 
 _SHM_NAME = "nanovllm_amd"
-_DIST_PORT = 2333        # same rendezvous port as the reference (model_runner.py:26)
+_DIST_PORT = 2333        # same rendezvous port as the reference (model_runner.py:26); NVL_TP_PORT overrides
+
+
+def _tp_port() -> int:
+    return int(os.environ.get("NVL_TP_PORT", os.environ.get("MASTER_PORT", _DIST_PORT)))
+
+
+class _Channel:
+    """Rank 0 -> workers control channel: a ring of message slots in POSIX shared memory.
+
+    Role of the reference's SharedMemory + Event + pickle protocol (model_runner.py:41-48,61-89), with two
+    differences: messages are a fixed binary header + raw staging-image bytes (no per-step pickling of
+    Sequence objects — SURVEY.md §8f rank 1), and it is a RING with per-worker read cursors instead of one
+    slot, so rank 0 can post decode step N+1 before a worker has picked up step N (decode lookahead).
+    Cursors are 8-byte aligned words written by exactly one process each; readers poll them (no mp.Event,
+    so workers started by torchrun rather than forked/spawned by rank 0 can attach by name)."""
+    SLOTS = 4
+    HDR = 128                      # head cursor + up to 8 tail cursors
+    MSG_HDR = 128                  # op, payload bytes, 8 int64 arguments
+
+    OP_EXIT, OP_PREFILL, OP_DECODE, OP_CALL = 0, 1, 2, 3
+
+    def __init__(self, name: str, slot_payload: int, world: int, create: bool):
+        from multiprocessing.shared_memory import SharedMemory
+        self.world = world
+        self.slot_bytes = _align(self.MSG_HDR + slot_payload, 64)
+        size = self.HDR + self.SLOTS * self.slot_bytes
+        if create:
+            try:
+                SharedMemory(name=name).unlink()           # stale segment from a crashed run
+            except FileNotFoundError:
+                pass
+            self.shm = SharedMemory(name=name, create=True, size=size)
+            self.shm.buf[:self.HDR] = bytes(self.HDR)
+        else:
+            deadline = time.time() + 120
+            while True:
+                try:
+                    self.shm = SharedMemory(name=name)
+                    break
+                except FileNotFoundError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.01)
+        self.owner = create
+        self.cur = np.frombuffer(self.shm.buf, dtype=np.int64, count=self.HDR // 8)   # [0] head, [1 + w] tails
+        self.buf = np.frombuffer(self.shm.buf, dtype=np.uint8)
+        self.sent = 0
+        self.seen = 0
+
+    def _slot(self, k: int):
+        off = self.HDR + (k % self.SLOTS) * self.slot_bytes
+        hdr = self.buf[off:off + self.MSG_HDR].view(np.int64)
+        return hdr, self.buf[off + self.MSG_HDR:off + self.slot_bytes]
+
+    # ---- rank 0 ----
+    def send(self, op: int, args=(), payload: np.ndarray | bytes | None = None) -> None:
+        tails = self.cur[1:self.world]
+        spins = 0
+        while self.sent - int(tails.min()) >= self.SLOTS:    # every slot still unread by some worker
+            spins += 1
+            if spins > 200:
+                time.sleep(0.00005)
+        hdr, body = self._slot(self.sent)
+        n = 0
+        if payload is not None:
+            src = np.frombuffer(payload, dtype=np.uint8) if isinstance(payload, (bytes, bytearray)) else payload
+            n = src.size
+            assert n <= body.size, "step message exceeds the control channel slot"
+            body[:n] = src
+        hdr[0], hdr[1] = op, n
+        for i, a in enumerate(args):
+            hdr[2 + i] = a
+        self.sent += 1
+        self.cur[0] = self.sent                                # publish (x86 keeps the store order)
+
+    # ---- workers ----
+    def recv(self):
+        """Block until the next message; returns (op, args[8], payload view). Call `ack()` once the payload
+        has been consumed."""
+        spins = 0
+        while int(self.cur[0]) <= self.seen:
+            spins += 1
+            if spins > 20000:
+                time.sleep(0.0001)
+        hdr, body = self._slot(self.seen)
+        return int(hdr[0]), hdr[2:10], body[:int(hdr[1])]
+
+    def ack(self, rank: int) -> None:
+        self.seen += 1
+        self.cur[rank] = self.seen                             # tail of worker `rank` lives at cur[rank], rank >= 1
+
+    def close(self) -> None:
+        self.cur = self.buf = None
+        try:
+            self.shm.close()
+            if self.owner:
+                self.shm.unlink()
+        except (BufferError, FileNotFoundError):
+            pass
 
 
 def _align(n: int, a: int = 16) -> int:
@@ -95,28 +200,52 @@ class _Stage:
 
 class ModelRunner:
 
-    def __init__(self, config: Config, rank: int, event):
+    def __init__(self, config: Config, rank: int, event=None):
+        """`event` is accepted for signature compatibility with the reference (model_runner.py:17) and unused:
+        the control channel is polled."""
         self.config = config
         hf = config.hf_config
         self.block_size = config.kvcache_block_size
         self.enforce_eager = config.enforce_eager
         self.world_size = config.tensor_parallel_size
         self.rank = rank
-        self.event = event
         assert torch.cuda.is_available(), "nano_vllm_amd needs a HIP device (no CPU fallback for the hot path)"
         ops.load_library()
 
+        # Devices: rank r drives GPU r, as the reference does (model_runner.py:27). NVL_TP_SHARE_GPU=1 puts every
+        # rank on GPU 0 — the functional test of the TP engine on a one-GPU box (with NVL_TP_BACKEND=gloo:
+        # RCCL refuses two ranks on one device).
+        share_gpu = os.environ.get("NVL_TP_SHARE_GPU") == "1"
+        dev_index = 0 if (share_gpu or self.world_size == 1) else int(os.environ.get("LOCAL_RANK", rank))
+        if self.world_size == 1:
+            dev_index = torch.cuda.current_device()
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
+        self._own_pg = False
         if self.world_size > 1:
-            dist.init_process_group("nccl", f"tcp://127.0.0.1:{_DIST_PORT}", world_size=self.world_size, rank=rank)
+            if dist.is_initialized():
+                # launched externally (torchrun: bench.py --tp N): the default group IS the TP group
+                assert dist.get_world_size() == self.world_size and dist.get_rank() == rank, \
+                    "an existing torch.distributed group must be the tensor-parallel group"
+            else:
+                backend = os.environ.get("NVL_TP_BACKEND", "nccl")
+                kw = dict(device_id=self.device) if backend == "nccl" else {}
+                dist.init_process_group(backend, f"tcp://127.0.0.1:{_tp_port()}", world_size=self.world_size,
+                                        rank=rank, **kw)
+                self._own_pg = True
         from .. import tp
         tp.init(rank if self.world_size > 1 else 0, self.world_size)
-        torch.cuda.set_device(rank)
-        self.device = torch.device("cuda", rank)
         self.geo = model_geometry(hf, self.world_size)
         dtype = self.geo["dtype"] or torch.bfloat16
         if isinstance(dtype, str):
             dtype = getattr(torch, dtype)
         assert dtype == torch.bfloat16, f"libnvl kernels are bf16 (config dtype {dtype})"
+        self.p2p = False
+        if self.world_size > 1:
+            # before the memory measurements below, so the comm buffers are accounted for
+            self.p2p = tp.init_p2p(min(config.max_num_seqs, 512), self.geo["hidden"], self.device)
+            if not tp.capturable():
+                self.enforce_eager = True          # gloo: collectives go through the host, nothing to capture
         prev_dtype = torch.get_default_dtype()
         torch.set_default_dtype(dtype)
         torch.set_default_device(self.device)
@@ -141,60 +270,73 @@ class ModelRunner:
             torch.set_default_device("cpu")
             torch.set_default_dtype(prev_dtype)
 
+        self.chan = None
         if self.world_size > 1:
-            from multiprocessing.shared_memory import SharedMemory
+            payload = max(self.dstage.nbytes, self.pstage.nbytes)
+            name = f"{_SHM_NAME}_{_tp_port()}"
             if rank == 0:
-                try:
-                    SharedMemory(name=_SHM_NAME).unlink()       # stale segment from a crashed run
-                except FileNotFoundError:
-                    pass
-                self.shm = SharedMemory(name=_SHM_NAME, create=True, size=2 ** 20)
+                self.chan = _Channel(name, payload, self.world_size, create=True)
                 dist.barrier()
             else:
                 dist.barrier()
-                self.shm = SharedMemory(name=_SHM_NAME)
+                self.chan = _Channel(name, payload, self.world_size, create=False)
                 self.loop()
 
-    # ------------------------------------------------------------------ lifecycle / TP RPC
+    # ------------------------------------------------------------------ lifecycle / TP control channel
     def exit(self):
-        if self.world_size > 1:
-            self.shm.close()
-            dist.barrier()
-            if self.rank == 0:
-                self.shm.unlink()
+        if self.world_size > 1 and self.rank == 0 and self.chan is not None:
+            self.chan.send(_Channel.OP_EXIT)
         self.graphs = {}
         torch.cuda.synchronize()
         if self.world_size > 1:
-            dist.destroy_process_group()
             from .. import tp
-            tp.init(0, 1)
+            if self.p2p:
+                tp.comm().status()            # raises if any P2P collective ever timed out waiting for a peer
+            dist.barrier()
+            if self.chan is not None:
+                self.chan.close()
+                self.chan = None
+            tp.shutdown()
+            if self._own_pg:
+                dist.destroy_process_group()
 
     def loop(self):
+        """Worker ranks: execute the steps rank 0 posts (model_runner.py:61-74)."""
+        ch = self.chan
         while True:
-            method, args = self._read_shm()
-            self.call(method, *args)
-            if method == "exit":
+            op, args, body = ch.recv()
+            if op == _Channel.OP_EXIT:
+                ch.ack(self.rank)
+                self.exit()
                 break
-
-    def _read_shm(self):
-        self.event.wait()
-        n = int.from_bytes(self.shm.buf[0:4], "little")
-        method, *args = pickle.loads(self.shm.buf[4:n + 4])
-        self.event.clear()
-        return method, args
-
-    def _write_shm(self, method, *args):
-        data = pickle.dumps([method, *args])
-        n = len(data)
-        assert n + 4 <= self.shm.size, "step message exceeds the 1 MiB control channel"
-        self.shm.buf[0:4] = n.to_bytes(4, "little")
-        self.shm.buf[4:n + 4] = data
-        for ev in self.event:
-            ev.set()
+            if op == _Channel.OP_DECODE:
+                n = int(args[0])
+                self.dstage.flip()
+                self.dstage.host.numpy()[:body.size] = body
+                ch.ack(self.rank)
+                self._launch_decode(n)
+                self._inflight.clear()             # workers never collect: their flight list is bookkeeping only
+            elif op == _Channel.OP_PREFILL:
+                info = dict(n=int(args[0]), ns=int(args[1]), max_q=int(args[2]), max_k=int(args[3]),
+                            paged=bool(args[4]), have_slots=bool(args[5]))
+                self.pstage.uploaded[0].synchronize()          # the previous prefill's upload has been consumed
+                self.pstage.host.numpy()[:body.size] = body
+                ch.ack(self.rank)
+                self._launch_prefill(info)
+            else:
+                method, *margs = pickle.loads(body.tobytes())
+                ch.ack(self.rank)
+                getattr(self, method)(*margs)
 
     def call(self, method, *args):
+        """Rank 0's entry point (model_runner.py:84-89). Steps are broadcast to the workers by the methods
+        themselves (as staging images); anything else goes through `call_all`."""
+        return getattr(self, method)(*args)
+
+    def call_all(self, method, *args):
+        """Run `method(*args)` on every rank (rare control calls; pickled)."""
         if self.world_size > 1 and self.rank == 0:
-            self._write_shm(method, *args)
+            self.chan.send(_Channel.OP_CALL, payload=pickle.dumps([method, *args]))
         return getattr(self, method)(*args)
 
     # ------------------------------------------------------------------ buffers
@@ -213,8 +355,8 @@ class ModelRunner:
             image["bt"][:] = -1
             image["src"][:] = -1
         self.dstage.upload()
-        # per pinned image: (seq id, #blocks) per decode row whose block-table row is current, rows in use
-        self._row_keys = [np.full((mb, 2), -1, dtype=np.int64) for _ in self.dstage.nps]
+        # per pinned image: (seq id, #blocks, allocation stamp) per decode row whose block-table row is current
+        self._row_keys = [np.full((mb, 3), -1, dtype=np.int64) for _ in self.dstage.nps]
         self._dirty = [0 for _ in self.dstage.nps]
         nt = cfg.max_num_batched_tokens
         ns = min(cfg.max_num_seqs, nt)
@@ -223,6 +365,12 @@ class ModelRunner:
             ("slots", np.int32, (nt,)), ("cu_q", np.int32, (ns + 1,)), ("cu_k", np.int32, (ns + 1,)),
             ("temps", np.float32, (ns,)), ("bt", np.int32, (ns, w)),
         ], self.device)
+        self.step_count = 0
+        self._inflight: list = []            # decode steps enqueued and not yet collected (at most two)
+        self._flight_parity = 0
+        self._last_rows: dict = {}
+        if self.device.type != "cuda":       # host-only instance (tests of the staging logic): no device buffers
+            return
         self.tokens_dev = torch.zeros(max(mb, ns), dtype=torch.int64, device=self.device)
         self.tokens_host = torch.zeros(max(mb, ns), dtype=torch.int64, device="cpu", pin_memory=True)
         self.tokens_host_b = torch.zeros(max(mb, ns), dtype=torch.int64, device="cpu", pin_memory=True)
@@ -230,13 +378,7 @@ class ModelRunner:
         # zeroed once: the kernel's arrival counters live in it and are left at zero by every launch
         self.decode_ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
         self.decode_ws_b = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
-        self.hidden_out = (torch.zeros(mb, self.geo["hidden"], dtype=torch.bfloat16, device=self.device)
-                           if self.world_size > 1 else None)
-        self.step_count = 0
-        self._inflight: list = []            # decode steps enqueued and not yet collected (at most two)
-        self._flight_parity = 0
         self._step_done = [torch.cuda.Event(), torch.cuda.Event()]
-        self._last_rows: dict = {}
 
     # ------------------------------------------------------------------ warm-up + KV cache
     def warmup_model(self):
@@ -250,7 +392,7 @@ class ModelRunner:
         seqs = [Sequence([0] * seq_len) for _ in range(num_seqs)]
         for s in seqs:
             s.num_scheduled_tokens = seq_len
-        self.run(seqs, True)
+        self._launch_prefill(self.prepare_prefill(seqs))       # every rank warms up on its own (same shapes)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
 
@@ -262,7 +404,15 @@ class ModelRunner:
         peak, current = stats["allocated_bytes.all.peak"], stats["allocated_bytes.all.current"]
         block_bytes = 2 * geo["layers"] * self.block_size * geo["kv_heads"] * geo["head_dim"] * 2
         if cfg.num_kvcache_blocks <= 0:
+            assert not (self.world_size > 1 and os.environ.get("NVL_TP_SHARE_GPU") == "1"), \
+                "ranks sharing one GPU cannot size the KV cache from free memory: pass num_kvcache_blocks"
             cfg.num_kvcache_blocks = int(total * cfg.gpu_memory_utilization - used - peak + current) // block_bytes
+        if self.world_size > 1:
+            # the scheduler (rank 0) must not hand out a block some rank does not have
+            from .. import tp
+            n = torch.tensor([cfg.num_kvcache_blocks], dtype=torch.int64)
+            tp.group_all_reduce(n, op=dist.ReduceOp.MIN)
+            cfg.num_kvcache_blocks = int(n.item())
         assert cfg.num_kvcache_blocks > 0, "no memory left for the KV cache"
         # zero-filled: masked tail rows of a block are multiplied by P == 0 in the decode kernel
         # Layer-major: a layer's K and V pools sit next to each other (the reference's [2, L, ...] puts them
@@ -279,9 +429,12 @@ class ModelRunner:
                 module.v_cache = self.kv_cache[1, layer]
                 layer += 1
 
-    # ------------------------------------------------------------------ batch preparation (host)
+    # ------------------------------------------------------------------ batch preparation (host, rank 0)
     def prepare_prefill(self, seqs: list[Sequence]) -> dict:
         """Fill the prefill staging block (semantics of model_runner.py:129-170)."""
+        ev = self.pstage.uploaded[0]
+        if ev is not None:
+            ev.synchronize()                                   # the previous prefill's upload has been consumed
         st, bs = self.pstage.np, self.block_size
         n = 0
         cu_q, cu_k = st["cu_q"], st["cu_k"]
@@ -318,8 +471,10 @@ class ModelRunner:
     def prepare_decode(self, seqs: list[Sequence], prev_rows: dict | None = None) -> int:
         """Fill the current pinned decode image (semantics of model_runner.py:172-188); returns bs.
         `prev_rows` (lookahead): seq_id -> row of the sequence in the decode step that is still in flight; the
-        input ids are then NOT staged — the graph's first node copies them from that step's sampled ids on the
-        device (nvl_feed_tokens) — and `src` carries the rows."""
+        input ids of those sequences are NOT staged — the graph's first node copies them from that step's
+        sampled ids on the device (nvl_feed_tokens) — and `src` carries the rows. A sequence that was not part
+        of the in-flight step (more running sequences than max_num_seqs: one finishes, the next one moves
+        up) gets src = -1 and its id staged: its last token came from an earlier, already collected step."""
         st, bs = self.dstage.np, self.block_size
         n = len(seqs)
         lens = np.fromiter((s.num_tokens for s in seqs), dtype=np.int64, count=n)
@@ -327,23 +482,29 @@ class ModelRunner:
             st["ids"][:n] = [s.last_token for s in seqs]
             st["src"][:n] = -1
         else:
-            st["src"][:n] = [prev_rows[s.seq_id] for s in seqs]
+            src = np.fromiter((prev_rows.get(s.seq_id, -1) for s in seqs), dtype=np.int32, count=n)
+            st["src"][:n] = src
+            for i in np.nonzero(src < 0)[0]:
+                st["ids"][i] = seqs[i].last_token
         st["pos"][:n] = lens - 1
         st["ctx"][:n] = lens
         last_blk = np.fromiter((s.block_table[-1] for s in seqs), dtype=np.int64, count=n)
         st["slots"][:n] = last_blk * bs + (lens - 1) % bs
         st["temps"][:n] = [s.temperature for s in seqs]
-        # block tables: rewrite a row only when its (sequence, #blocks) changed in THIS image
+        # block tables: rewrite a row only when its (sequence, #blocks, allocation stamp) changed in THIS image.
+        # The stamp matters: a preempted sequence that is prefilled again may come back to the same row with the
+        # same number of blocks but other block ids (kv_blocks.BlockManager.allocate).
         key = self._row_keys[self.dstage.cur]
         ids = np.fromiter((s.seq_id for s in seqs), dtype=np.int64, count=n)
         nblk = np.fromiter((len(s.block_table) for s in seqs), dtype=np.int64, count=n)
-        stale = np.nonzero((key[:n, 0] != ids) | (key[:n, 1] != nblk) | (ids < 0))[0]
+        gen = np.fromiter((s.table_gen for s in seqs), dtype=np.int64, count=n)
+        stale = np.nonzero((key[:n, 0] != ids) | (key[:n, 1] != nblk) | (key[:n, 2] != gen) | (ids < 0))[0]
         bt = st["bt"]
         for i in stale:
             t = seqs[i].block_table
             bt[i, :len(t)] = t
             bt[i, len(t):] = -1
-        key[:n, 0], key[:n, 1] = ids, nblk
+        key[:n, 0], key[:n, 1], key[:n, 2] = ids, nblk, gen
         # neutralise rows used by a previous, larger batch (graph padding: slot -1, context 0)
         dirty = self._dirty[self.dstage.cur]
         if dirty > n:
@@ -358,24 +519,29 @@ class ModelRunner:
         self.step_count += 1
         st.np["rng"][0] = self.step_count
 
+    def _sample(self, hidden, temps, out, rng, sampler):
+        """lm_head + sampler on the current stream; TP > 1: every rank samples its vocabulary shard and the
+        per-row winners are merged on every rank (no [B, V] gather, embed_head.py:62-65)."""
+        if self.world_size == 1:
+            sampler(self.model.compute_logits(hidden), temps, out=out, offset_dev=rng)
+        else:
+            logits = self.model.compute_logits_shard(hidden)
+            sampler.forward_shard(logits, temps, self.rank * self.geo["vocab_per_rank"], out, offset_dev=rng)
+
     def _decode_rows(self, r0: int, r1: int, ws, sampler):
         """Decode forward for rows [r0, r1) of the static device buffers, on the current stream."""
         t = self.dstage.t
         set_context(False, slot_mapping=t["slots"][r0:r1], context_lens=t["ctx"][r0:r1],
                     block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len)
         hidden = self.model(t["ids"][r0:r1], t["pos"][r0:r1])
-        if self.world_size == 1:
-            logits = self.model.compute_logits(hidden)
-            sampler(logits, t["temps"][r0:r1], out=self.tokens_dev[r0:r1], offset_dev=t["rng"][:1])
-        else:
-            self.hidden_out[r0:r1].copy_(hidden)
+        self._sample(hidden, t["temps"][r0:r1], self.tokens_dev[r0:r1], t["rng"][:1], sampler)
         reset_context()
 
     @torch.inference_mode()
     def _forward_decode(self, bs: int):
-        """Decode forward on the static device buffers (captured per bucket, or run eagerly).
-        TP=1: layers + lm_head + sampler. TP>1: layers only (the logits gather to rank 0 and the
-        sampler run eagerly in `_decode_tail`, as in the reference, model_runner.py:212,218).
+        """Decode forward on the static device buffers (captured per bucket, or run eagerly): layers + lm_head
+        + sampler, at any TP degree (the reference captures the layers only and runs lm_head, the logits
+        gather and the sampler eagerly, model_runner.py:212,218).
 
         Micro-batching (NVL_MICROBATCHES=2, off by default; TP=1, bs >= 32): sequences are independent, so
         the batch can be cut into two half-batches whose layer chains are forked onto two HIP streams (two
@@ -401,32 +567,14 @@ class ModelRunner:
             self._decode_rows(0, bs, self.decode_ws, self.sampler)
 
     @torch.inference_mode()
-    def _decode_tail(self, bs: int):
-        t = self.dstage.t
-        set_context(False)
-        logits = self.model.compute_logits(self.hidden_out[:bs])
-        if self.rank == 0:
-            self.sampler(logits, t["temps"][:bs], out=self.tokens_dev[:bs], offset_dev=t["rng"][:1])
-        reset_context()
-
-    @torch.inference_mode()
-    def decode_begin(self, seqs: list[Sequence], staged: bool = False) -> int:
-        """Enqueue one decode step (H2D of the staging image, graph replay or eager forward, D2H of the
-        sampled ids) and return without waiting; up to two steps may be in flight. `staged`: the image was
-        already filled by `stage_next_decode` (lookahead)."""
-        if not staged:
-            self.dstage.flip()
-            self.prepare_decode(seqs)
-        n = len(seqs)
-        self._next_rng(self.dstage)
+    def _launch_decode(self, n: int) -> None:
+        """Every rank: upload the current image, run the step, start the D2H of the ids (rank 0)."""
         self.dstage.upload()
         bucket = next((b for b in self.graph_bs if b >= n), None) if self.graphs else None
         if bucket is not None:
             self.graphs[bucket].replay()
         else:
             self._forward_decode(n)
-        if self.world_size > 1:
-            self._decode_tail(n)
         host = self.tokens_host if self._flight_parity == 0 else self.tokens_host_b
         done = self._step_done[self._flight_parity]
         if self.rank == 0:
@@ -434,14 +582,27 @@ class ModelRunner:
         done.record()
         self._inflight.append((n, host, done))
         self._flight_parity ^= 1
+
+    def decode_begin(self, seqs: list[Sequence], staged: bool = False) -> int:
+        """Enqueue one decode step on every rank (H2D of the staging image, graph replay or eager forward,
+        D2H of the sampled ids) and return without waiting; up to two steps may be in flight. `staged`: the
+        image was already filled by `stage_next_decode` (lookahead)."""
+        if not staged:
+            self.dstage.flip()
+            self.prepare_decode(seqs)
+        n = len(seqs)
+        self._next_rng(self.dstage)
+        if self.chan is not None:
+            self.chan.send(_Channel.OP_DECODE, (n,), self.dstage.host.numpy())
+        self._launch_decode(n)
         self._last_rows = {s.seq_id: i for i, s in enumerate(seqs)}
         return n
 
     def decode_end(self) -> list[int] | None:
-        """Wait for the OLDEST step enqueued by `decode_begin` and return its sampled ids (rank 0)."""
+        """Wait for the OLDEST step enqueued by `decode_begin` and return its sampled ids."""
         n, host, done = self._inflight.pop(0)
         done.synchronize()
-        return host[:n].tolist() if self.rank == 0 else None
+        return host[:n].tolist()
 
     def stage_next_decode(self, seqs: list[Sequence]) -> None:
         """Lookahead: fill the other pinned image for the NEXT decode step while the step just enqueued runs
@@ -454,20 +615,27 @@ class ModelRunner:
         return self.decode_end()
 
     @torch.inference_mode()
-    def _run_prefill(self, seqs: list[Sequence]) -> list[int] | None:
-        info = self.prepare_prefill(seqs)
-        self._next_rng(self.pstage)
+    def _launch_prefill(self, info: dict) -> None:
+        """Every rank: upload the prefill image and run the step (ids of each sequence's last token land in
+        tokens_dev[:ns] on every rank)."""
         self.pstage.upload()
         t = self.pstage.t
         n, ns = info["n"], info["ns"]
         set_context(True, t["cu_q"][:ns + 1], t["cu_k"][:ns + 1], info["max_q"], info["max_k"],
                     t["slots"][:n] if info["have_slots"] else None, None, t["bt"][:ns] if info["paged"] else None)
         hidden = self.model(t["ids"][:n], t["pos"][:n])
-        logits = self.model.compute_logits(hidden)
+        self._sample(hidden, t["temps"][:ns], self.tokens_dev[:ns], t["rng"][:1], self.sampler)
         reset_context()
-        if self.rank != 0:
-            return None
-        self.sampler(logits, t["temps"][:ns], out=self.tokens_dev[:ns], offset_dev=t["rng"][:1])
+
+    def _run_prefill(self, seqs: list[Sequence]) -> list[int] | None:
+        info = self.prepare_prefill(seqs)
+        self._next_rng(self.pstage)
+        if self.chan is not None:
+            self.chan.send(_Channel.OP_PREFILL, (info["n"], info["ns"], info["max_q"], info["max_k"],
+                                                 int(info["paged"]), int(info["have_slots"])),
+                           self.pstage.host.numpy())
+        self._launch_prefill(info)
+        ns = info["ns"]
         self.tokens_host[:ns].copy_(self.tokens_dev[:ns], non_blocking=True)
         torch.cuda.current_stream().synchronize()
         return self.tokens_host[:ns].tolist()
@@ -479,7 +647,8 @@ class ModelRunner:
     @torch.inference_mode()
     def capture_graphs(self):
         """One graph per batch bucket, largest first so the pool is sized once
-        (buckets as model_runner.py:234)."""
+        (buckets as model_runner.py:234). TP > 1: every rank captures the same sequence of launches, including
+        the xGMI collectives (enqueue-only kernels whose epochs live in device memory)."""
         max_bs = min(self.max_bs, 512)
         self.graph_bs = [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
         pool = None

@@ -5,7 +5,7 @@ Appendix A.1): a step is either all-prefill or all-decode; prefill has absolute 
 admits head-of-line sequences FIFO under `max_num_seqs` / `max_num_batched_tokens`, chunking
 only the first sequence of a batch; decode preempts from the tail (recompute) when the block
 pool is exhausted. Equivalence with the imported reference is tested on random traces
-(tests/test_host_logic_vs_reference.py) — outputs and prefix-cache reuse depend on it.
+(tests/test_host_logic.py: golden traces recorded from the imported reference + a live-reference test) — outputs and prefix-cache reuse depend on it.
 
 Host-path changes that do not alter behaviour: finished sequences leave `running` through an
 identity filter instead of deque.remove per sequence, and the running queue is a plain list

@@ -23,8 +23,8 @@ class SequenceStatus(Enum):
 
 class Sequence:
     __slots__ = ("seq_id", "status", "token_ids", "last_token", "num_tokens", "num_prompt_tokens",
-                 "num_cached_tokens", "num_scheduled_tokens", "is_prefill", "block_table", "temperature",
-                 "max_tokens", "ignore_eos")
+                 "num_cached_tokens", "num_scheduled_tokens", "is_prefill", "block_table", "table_gen",
+                 "temperature", "max_tokens", "ignore_eos")
 
     block_size = 256          # set by the engine from Config.kvcache_block_size
     counter = count()
@@ -41,6 +41,7 @@ class Sequence:
         self.num_scheduled_tokens = 0
         self.is_prefill = True
         self.block_table: list[int] = []
+        self.table_gen = 0            # stamped by BlockManager.allocate: distinguishes re-allocations of the same length
         self.temperature = sp.temperature
         self.max_tokens = sp.max_tokens
         self.ignore_eos = sp.ignore_eos
@@ -89,11 +90,11 @@ class Sequence:
     def __getstate__(self):
         payload = self.token_ids if self.is_prefill else self.last_token
         return (self.seq_id, self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens,
-                self.num_scheduled_tokens, self.block_table, payload)
+                self.num_scheduled_tokens, self.block_table, self.table_gen, payload)
 
     def __setstate__(self, state):
         (self.seq_id, self.num_tokens, self.num_prompt_tokens, self.num_cached_tokens, self.num_scheduled_tokens,
-         self.block_table, payload) = state
+         self.block_table, self.table_gen, payload) = state
         if isinstance(payload, list):
             self.token_ids, self.last_token = payload, payload[-1]
         else:

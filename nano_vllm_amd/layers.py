@@ -28,6 +28,15 @@ from .attn_meta import get_context
 
 
 # ------------------------------------------------------------------------------------------------
+class PartialSum:
+    """A row-parallel GEMM output that has NOT been all-reduced yet: the consumer (RMSNorm.forward with a
+    residual) performs the reduction fused with its own arithmetic."""
+    __slots__ = ("t",)
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+
+
 class RMSNorm(nn.Module):
     """y = bf16(x32 * rsqrt(mean x32^2 + eps) * w32); with `residual`: fused add, residual updated."""
 
@@ -40,6 +49,10 @@ class RMSNorm(nn.Module):
         if residual is None:
             return ops.rmsnorm(x, self.weight, self.eps)
         # the reference returns (normed, bf16(x + residual)); we update `residual` in place
+        if isinstance(x, PartialSum):
+            # x = this rank's bf16 partial sums of a RowParallelLinear (`forward_decode`, TP > 1): the all-reduce
+            # over xGMI and this norm are one launch (tp.all_reduce_add_rmsnorm)
+            return tp.all_reduce_add_rmsnorm(x.t, residual, self.weight, self.eps), residual
         if x.dtype == torch.float32 and x.dim() == 3:
             # x = fp32 split-K partials [S, N, hidden] of a decode-step RowParallelLinear
             # (`forward_decode`): the slab sum is this kernel's prologue
@@ -171,6 +184,29 @@ class Sampler(nn.Module):
         self.calls += 1
         return ops.sample(logits, temperatures, self.seed, offset, self._ws, out=out, offset_dev=offset_dev)
 
+    def forward_shard(self, logits: torch.Tensor, temperatures: torch.Tensor, col_offset: int, out: torch.Tensor,
+                      offset_dev: torch.Tensor | None = None) -> torch.Tensor:
+        """Vocab-parallel sampling (TP > 1): `logits` is this rank's [B, V/tp] shard starting at global column
+        `col_offset`. Each rank reduces its shard to one {key, index} pair per row, the pairs (8 B per row)
+        are all-gathered over xGMI and merged — same draw as `forward` on the gathered logits, on EVERY rank,
+        without the reference's [B, V] gather to rank 0 (embed_head.py:62-65)."""
+        b = logits.shape[0]
+        _, size = tp.world()
+        need = ops.sample_workspace_bytes(max(b, 512))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != logits.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=logits.device)
+        if getattr(self, "_pairs", None) is None or self._pairs.shape[1] < b or self._pairs.device != logits.device:
+            rows = max(b, 512)
+            self._mine = torch.zeros((rows, 2), dtype=torch.int32, device=logits.device)
+            self._pairs = torch.zeros((size, rows, 2), dtype=torch.int32, device=logits.device)
+        offset = 0 if offset_dev is not None else self.calls
+        self.calls += 1
+        rows = self._mine.shape[0]
+        # whole fixed-size buffers travel (4 KiB at 512 rows): shape-independent => graph-safe
+        ops.sample_shard(logits, temperatures, col_offset, self.seed, offset, self._ws, self._mine, offset_dev=offset_dev)
+        tp.all_gather_small(self._mine, self._pairs)
+        return ops.sample_merge(self._pairs, size, b, out)
+
 
 # ------------------------------------------------------------------------------------------------
 # TP-sharded linears. Shard layout follows layers/linear.py:54-156 (SURVEY.md Appendix A.4).
@@ -295,16 +331,27 @@ class RowParallelLinear(LinearBase):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.tp_size == 1:
             return LinearBase.forward(self, x)
-        return tp.linear_allreduce(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        bias = self.bias if self.tp_rank == 0 else None
+        if bias is None and _decode_sized(x):
+            return tp.all_reduce(LinearBase.forward(self, x))
+        return tp.linear_allreduce(x, self.weight, bias)
 
-    def forward_decode(self, x: torch.Tensor) -> torch.Tensor:
-        """Like forward, but on decode-sized inputs (TP=1) may return the GEMM's fp32 split-K partials
-        [S, N, out] instead of the bf16 sum; the only consumer is RMSNorm.forward(x, residual), which
-        sums and rounds them in its prologue."""
+    def forward_decode(self, x: torch.Tensor):
+        """Like forward, but the result may come back UNREDUCED for the consumer to finish — the only consumer
+        is RMSNorm.forward(x, residual):
+          TP = 1, decode-sized: the GEMM's fp32 split-K partials [S, N, out] (summed + rounded in the norm's
+                  prologue);
+          TP > 1, message fits the P2P comm buffer: this rank's bf16 partial sums as `PartialSum` (the xGMI
+                  all-reduce is fused with the residual-add + RMSNorm)."""
         n, k = self.weight.shape
-        if (self.tp_size == 1 and self.bias is None and _decode_sized(x)
-                and ops.linear_decode_splits(x.shape[0], n, k, ops.LINEAR_PARTIAL)):
-            return ops.linear_decode(x, self.weight, ops.LINEAR_PARTIAL)
+        if self.tp_size == 1:
+            if (self.bias is None and _decode_sized(x)
+                    and ops.linear_decode_splits(x.shape[0], n, k, ops.LINEAR_PARTIAL)):
+                return ops.linear_decode(x, self.weight, ops.LINEAR_PARTIAL)
+            return self.forward(x)
+        c = tp.comm()
+        if c is not None and self.bias is None and x.dim() == 2 and c.fits(x.shape[0], n):
+            return PartialSum(LinearBase.forward(self, x))
         return self.forward(x)
 
 
@@ -346,7 +393,21 @@ class ParallelLMHead(VocabParallelEmbedding):
         logits = F.linear(x, self.weight)
         if self.tp_size == 1:
             return logits
+        # reference-shaped result (full logits on rank 0, None elsewhere, embed_head.py:62-65). The engine
+        # itself never takes this path at TP > 1: it samples from the shards (forward_shard + Sampler.forward_shard)
         import torch.distributed as dist
+        if dist.get_backend() == "gloo" and logits.is_cuda:        # gloo has no device gather
+            host = logits.cpu()
+            parts = [torch.empty_like(host) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
+            dist.gather(host, parts, 0)
+            return torch.cat(parts, -1).to(logits.device) if self.tp_rank == 0 else None
         parts = [torch.empty_like(logits) for _ in range(self.tp_size)] if self.tp_rank == 0 else None
         dist.gather(logits, parts, 0)
         return torch.cat(parts, -1) if self.tp_rank == 0 else None
+
+    def forward_shard(self, x: torch.Tensor) -> torch.Tensor:
+        """This rank's [S, V/tp] logits (columns vocab_start_idx ...), no collective."""
+        ctx = get_context()
+        if ctx.is_prefill:
+            x = x[(ctx.cu_seqlens_q[1:] - 1).long()].contiguous()
+        return F.linear(x, self.weight)

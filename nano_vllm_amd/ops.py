@@ -47,7 +47,20 @@ SIGNATURES = {
     "nvl_sample_workspace_bytes": (c_size_t, [c_int64]),
     "nvl_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_void_p,
                            c_void_p, c_size_t, c_void_p]),
+    "nvl_sample_shard": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64,
+                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+    "nvl_sample_merge": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "nvl_feed_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "nvl_allreduce_create": (c_int, [c_int, c_int, c_int64, ctypes.POINTER(c_void_p)]),
+    "nvl_allreduce_uid": (c_int, [c_void_p, c_void_p]),
+    "nvl_allreduce_connect": (c_int, [c_void_p, c_void_p]),
+    "nvl_allreduce_max_bytes": (c_int64, [c_void_p]),
+    "nvl_allreduce_run": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "nvl_allreduce_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
+                                          c_void_p]),
+    "nvl_allreduce_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "nvl_allreduce_status": (c_int, [c_void_p]),
+    "nvl_allreduce_destroy": (c_int, [c_void_p]),
     "nvl_sample_exponentials_host": (None, [c_uint64, c_uint64, c_int64, c_int64, c_int64, c_void_p]),
 }
 
@@ -329,6 +342,87 @@ def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: 
                             offset_dev.data_ptr() if offset_dev is not None else None, workspace.data_ptr(),
                             workspace.numel() * workspace.element_size(), _stream()))
     return out
+
+
+def sample_shard(logits: torch.Tensor, temperatures: torch.Tensor, col_offset: int, seed: int, offset: int,
+                 workspace: torch.Tensor, out_packed: torch.Tensor, offset_dev: torch.Tensor | None = None) -> torch.Tensor:
+    """This rank's vocabulary shard -> one {key bits, global index} pair per row (int32 [B, 2])."""
+    _dev(logits, "logits")
+    assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype == torch.bfloat16
+    assert temperatures.dtype == torch.float32 and out_packed.dtype == torch.int32 and out_packed.is_contiguous()
+    b, vocab = logits.shape
+    assert out_packed.numel() >= 2 * b
+    _check(lib().nvl_sample_shard(logits.data_ptr(), logits.stride(0), temperatures.data_ptr(), out_packed.data_ptr(), b,
+                                  vocab, col_offset, seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF,
+                                  offset_dev.data_ptr() if offset_dev is not None else None, workspace.data_ptr(),
+                                  workspace.numel() * workspace.element_size(), _stream()))
+    return out_packed
+
+
+def sample_merge(packed: torch.Tensor, parts: int, batch: int, out: torch.Tensor) -> torch.Tensor:
+    """packed int32 [parts, >= batch, 2] (contiguous rows) -> out int64 [batch]: index of the largest key."""
+    _dev(packed, "packed")
+    assert packed.dtype == torch.int32 and packed.dim() == 3 and packed.shape[0] == parts and packed.shape[2] == 2
+    assert packed.stride(2) == 1 and packed.stride(1) == 2 and out.dtype == torch.int64
+    _check(lib().nvl_sample_merge(packed.data_ptr(), parts, packed.stride(0) * 4, out.data_ptr(), batch, _stream()))
+    return out
+
+
+class P2PComm:
+    """Handle of the hand-written xGMI collectives (csrc/comm.hip). Construction is collective:
+    `exchange(bytes) -> list[bytes]` must all-gather a 64-byte token across the tensor-parallel ranks
+    and `barrier()` must synchronise them (both host-side, out of band)."""
+
+    def __init__(self, rank: int, world: int, max_bytes: int, exchange, barrier):
+        self.rank, self.world = rank, world
+        h = c_void_p()
+        _check(lib().nvl_allreduce_create(rank, world, max_bytes, ctypes.byref(h)))
+        self._h = h
+        uid = ctypes.create_string_buffer(64)
+        _check(lib().nvl_allreduce_uid(self._h, uid))
+        uids = exchange(uid.raw)
+        assert len(uids) == world and all(len(u) == 64 for u in uids)
+        blob = ctypes.create_string_buffer(b"".join(uids), 64 * world)
+        _check(lib().nvl_allreduce_connect(self._h, blob))
+        barrier()
+        self.max_bytes = int(lib().nvl_allreduce_max_bytes(self._h))
+
+    def fits(self, rows: int, hidden: int) -> bool:
+        return rows * hidden * 2 <= self.max_bytes and hidden % (8 * self.world) == 0 and hidden <= 8192
+
+    def all_reduce(self, x: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        _dev(x, "x")
+        assert x.dim() == 2 and x.is_contiguous() and x.dtype == torch.bfloat16
+        out = x if out is None else out
+        _check(lib().nvl_allreduce_run(self._h, x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _stream()))
+        return out
+
+    def all_reduce_add_rmsnorm(self, x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                               out: torch.Tensor | None = None) -> torch.Tensor:
+        _dev(x, "x")
+        assert x.dim() == 2 and x.is_contiguous() and residual.is_contiguous() and x.shape == residual.shape
+        assert x.dtype == torch.bfloat16 and residual.dtype == torch.bfloat16
+        if out is None:
+            out = torch.empty_like(x)
+        _check(lib().nvl_allreduce_add_rmsnorm(self._h, x.data_ptr(), residual.data_ptr(), weight.data_ptr(),
+                                               out.data_ptr(), x.shape[0], x.shape[1], eps, _stream()))
+        return out
+
+    def all_gather(self, x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+        """out[world, nbytes(x)] <- every rank's x (nbytes a multiple of 16, <= 4096)."""
+        _dev(x, "x")
+        n = x.numel() * x.element_size()
+        assert x.is_contiguous() and out.is_contiguous() and out.numel() * out.element_size() >= n * self.world
+        _check(lib().nvl_allreduce_gather(self._h, x.data_ptr(), out.data_ptr(), n, _stream()))
+        return out
+
+    def status(self) -> None:
+        _check(lib().nvl_allreduce_status(self._h))
+
+    def close(self) -> None:
+        if self._h is not None:
+            lib().nvl_allreduce_destroy(self._h)
+            self._h = None
 
 
 def feed_tokens(ids: torch.Tensor, src_row: torch.Tensor, prev_tokens: torch.Tensor) -> None:

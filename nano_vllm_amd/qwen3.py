@@ -129,3 +129,7 @@ class Qwen3ForCausalLM(nn.Module):
 
     def compute_logits(self, hidden_states: torch.Tensor) -> torch.Tensor:
         return self.lm_head(hidden_states)
+
+    def compute_logits_shard(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        """This rank's vocabulary slice of the logits (TP > 1: sampled shard-wise, never gathered)."""
+        return self.lm_head.forward_shard(hidden_states)

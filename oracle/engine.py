@@ -4,7 +4,7 @@ scheduler + block manager + runner batch layout + generate(), driving oracle/mod
 Deliberately naive and close to the reference's semantics, written
 as one small state machine over plain dict records. File:line citations are into
 GeeeekExplorer/nano-vllm v0.2.0. Validated against the imported reference's own
-Scheduler / BlockManager in tests/test_host_logic_vs_reference.py.
+Scheduler / BlockManager in tests/test_host_logic.py.
 """
 from __future__ import annotations
 

@@ -1,0 +1,249 @@
+"""Host side of the engine on CPU: the REAL LLMEngine loop (`_step_lookahead`), scheduler, block manager and
+ModelRunner staging code (`prepare_prefill`, `prepare_decode`, `decode_begin`, `stage_next_decode`) driven by a
+stand-in for the device: the "model" is a deterministic function of (input id, position) evaluated on the
+staged images exactly as the device would consume them (including nvl_feed_tokens' row indirection).
+
+Checks, on workloads with more prompts than max_num_seqs, ragged output lengths, chunked prefill and a block
+pool small enough to force preemption:
+  * the lookahead loop and the strictly serial loop produce identical outputs;
+  * every staged decode image agrees with its sequences (ids after the feed, positions, context lengths, slots,
+    and the block-table rows — which are cached per row and must be refreshed when a preempted sequence comes
+    back with other block ids);
+  * requests that cannot fit max_model_len are refused up front.
+Plus the rank-0 -> workers control channel (ring of slots in shared memory).
+"""
+import os
+import threading
+import time
+from random import Random
+
+import numpy as np
+import pytest
+import torch
+
+from nano_vllm_amd.api import Config, SamplingParams
+from nano_vllm_amd.engine.core import LLMEngine
+from nano_vllm_amd.engine.runner import ModelRunner, _Channel
+from nano_vllm_amd.engine.sched import Scheduler
+from nano_vllm_amd.engine.seq import Sequence
+
+VOCAB = 1000
+
+
+def _next_token(ids, pos):
+    return (np.asarray(ids, dtype=np.int64) * 1103515245 + np.asarray(pos, dtype=np.int64) * 12345 + 1) % VOCAB
+
+
+class _HF:
+    num_attention_heads, num_key_value_heads, hidden_size, num_hidden_layers = 4, 2, 512, 2
+    intermediate_size, vocab_size, rms_norm_eps, max_position_embeddings = 512, VOCAB, 1e-6, 4096
+    head_dim, tie_word_embeddings, torch_dtype = 128, True, "bfloat16"
+
+
+class FakeRunner(ModelRunner):
+    """ModelRunner with the device replaced by `_next_token`; all staging code is the product's."""
+
+    def __init__(self, config):
+        self.config = config
+        self.block_size = config.kvcache_block_size
+        self.world_size, self.rank, self.chan = 1, 0, None
+        self.device = torch.device("cpu")
+        self.geo = dict(heads=4, kv_heads=2, hidden=512, layers=2)
+        self.graphs = {}
+        self._alloc_stages()
+        self.tokens = np.zeros(config.max_num_seqs + 8, dtype=np.int64)       # "tokens_dev"
+        self.checked_rows = 0
+        self._cur = None
+
+    def decode_begin(self, seqs, staged=False):
+        self._cur = list(seqs)
+        return super().decode_begin(seqs, staged)
+
+    def _launch_decode(self, n):
+        st = self.dstage.np
+        seqs = self._cur
+        assert len(seqs) == n
+        ids = st["ids"][:n].copy()
+        src = st["src"][:n]
+        fed = src >= 0
+        ids[fed] = self.tokens[src[fed]]                   # nvl_feed_tokens
+        bs = self.block_size
+        for i, s in enumerate(seqs):
+            # with the lookahead the newest token value may still be a placeholder on the host: the id must then
+            # come from the device feed; everything else is known
+            if s.last_token != Scheduler.PLACEHOLDER:
+                assert ids[i] == s.last_token, (i, ids[i], s.last_token)
+            assert st["pos"][i] == s.num_tokens - 1 and st["ctx"][i] == s.num_tokens
+            assert st["slots"][i] == s.block_table[-1] * bs + (s.num_tokens - 1) % bs
+            row = st["bt"][i]
+            assert list(row[:len(s.block_table)]) == s.block_table, (i, s.seq_id, list(row[:8]), s.block_table)
+            assert (row[len(s.block_table):] == -1).all()
+            self.checked_rows += 1
+        assert (st["ctx"][n:self.max_bs] == 0).all() and (st["slots"][n:self.max_bs] == -1).all()
+        toks = _next_token(ids, st["pos"][:n])
+        self.tokens[:n] = toks
+        self._inflight.append((n, toks.copy()))
+
+    def decode_end(self):
+        n, toks = self._inflight.pop(0)
+        return toks.tolist()
+
+    def _run_prefill(self, seqs):
+        info = self.prepare_prefill(seqs)
+        st = self.pstage.np
+        cu = st["cu_q"][:info["ns"] + 1]
+        last = cu[1:] - 1
+        toks = _next_token(st["ids"][last], st["pos"][last])
+        n = 0
+        for i, s in enumerate(seqs):                        # staged chunk == the sequence's scheduled tokens
+            lq = s.num_scheduled_tokens
+            assert list(st["ids"][n:n + lq]) == s.token_ids[s.num_cached_tokens:s.num_cached_tokens + lq]
+            n += lq
+        self.tokens[:info["ns"]] = toks
+        return toks.tolist()
+
+    def exit(self):
+        pass
+
+
+def _engine(lookahead: bool, **cfg_kw):
+    Sequence.counter = __import__("itertools").count()
+    cfg = Config(os.path.dirname(__file__), hf_config=_HF(), **cfg_kw)
+    eng = LLMEngine.__new__(LLMEngine)
+    eng.config = cfg
+    Sequence.block_size = cfg.kvcache_block_size
+    eng.ps = []
+    eng.model_runner = FakeRunner(cfg)
+    eng.tokenizer = None
+    eng.scheduler = Scheduler(cfg)
+    eng._lookahead = lookahead
+    eng._unfilled = None
+    eng._exited = True
+    return eng
+
+
+def _generate(eng, prompts, sps):
+    for p, sp in zip(prompts, sps):
+        eng.add_request(p, sp)
+    done = {}
+    pending = None
+    steps = 0
+    while not eng.is_finished() or pending is not None or eng._unfilled is not None:
+        finished, _, pending = eng._step_lookahead(pending)
+        for sid, toks in finished:
+            done[sid] = list(toks)
+        steps += 1
+        assert steps < 100000
+    return [done[k] for k in sorted(done)]
+
+
+def _workload(seed, n, lo, hi, out_lo, out_hi):
+    r = Random(seed)
+    prompts = [[r.randint(0, VOCAB - 1) for _ in range(r.randint(lo, hi))] for _ in range(n)]
+    sps = [SamplingParams(temperature=0.0, ignore_eos=True, max_tokens=r.randint(out_lo, out_hi)) for _ in range(n)]
+    return prompts, sps
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_lookahead_equals_serial_with_more_prompts_than_rows(seed):
+    """running > max_num_seqs => a sequence that was NOT in the in-flight step enters the next
+    one; its id must be staged, not looked up in the in-flight step's rows."""
+    prompts, sps = _workload(seed, 14, 3, 40, 1, 9)
+    kw = dict(max_num_seqs=4, max_model_len=1024, num_kvcache_blocks=64, max_num_batched_tokens=64)
+    a = _engine(True, **kw)
+    out_a = _generate(a, prompts, sps)
+    b = _engine(False, **kw)
+    out_b = _generate(b, prompts, sps)
+    assert out_a == out_b
+    assert [len(t) for t in out_a] == [sp.max_tokens for sp in sps]
+    assert a.model_runner.checked_rows > 0
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_staged_block_tables_under_preemption(seed):
+    """tiny block pool, sequences crossing block boundaries => preemption + re-prefill with
+    prefix-cache revival; every staged block-table row must equal its sequence's table (checked by FakeRunner on
+    every decode row), in both host loops, and the outputs must agree."""
+    r = Random(100 + seed)
+    shared = [r.randint(0, VOCAB - 1) for _ in range(256)]
+    prompts, sps = [], []
+    for i in range(10):
+        tail = [r.randint(0, VOCAB - 1) for _ in range(r.randint(200, 300))]
+        prompts.append((shared if i % 2 == 0 else []) + tail)
+        sps.append(SamplingParams(temperature=0.0, ignore_eos=True, max_tokens=r.randint(40, 120)))
+    kw = dict(max_num_seqs=6, max_model_len=2048, num_kvcache_blocks=12, max_num_batched_tokens=700)
+    a = _engine(True, **kw)
+    preempts = []
+    orig = a.scheduler.preempt
+    a.scheduler.preempt = lambda s: (preempts.append(s.seq_id), orig(s))[1]
+    out_a = _generate(a, prompts, sps)
+    out_b = _generate(_engine(False, **kw), prompts, sps)
+    assert out_a == out_b
+    assert preempts, "workload must preempt"
+
+
+def test_row_cache_is_refreshed_when_a_sequence_returns_with_other_blocks():
+    """The exact ADVICE scenario, constructed: same row, same sequence id, same NUMBER of blocks, other ids."""
+    eng = _engine(False, max_num_seqs=4, max_model_len=1024, num_kvcache_blocks=16)
+    runner = eng.model_runner
+    s = Sequence(list(range(300)), SamplingParams(temperature=0.0, ignore_eos=True, max_tokens=8))
+    bm = eng.scheduler.block_manager
+    bm.allocate(s, 0)
+    first = list(s.block_table)
+    for img in range(2):
+        runner.dstage.flip()
+        runner.prepare_decode([s])
+        assert list(runner.dstage.np["bt"][0, :2]) == first
+    bm.deallocate(s)
+    other = Sequence(list(range(1000, 1300)))
+    bm.allocate(other, 0)                                   # takes the head of the free list
+    bm.allocate(s, 0)
+    assert len(s.block_table) == len(first) and s.block_table != first
+    for img in range(2):
+        runner.dstage.flip()
+        runner.prepare_decode([s])
+        assert list(runner.dstage.np["bt"][0, :2]) == s.block_table
+
+
+def test_over_length_request_is_refused_up_front():
+    eng = _engine(True, max_num_seqs=4, max_model_len=512, num_kvcache_blocks=8)
+    with pytest.raises(AssertionError, match="max_model_len"):
+        eng.add_request(list(range(500)), SamplingParams(max_tokens=13))
+    eng.add_request(list(range(500)), SamplingParams(max_tokens=12))
+
+
+def test_control_channel_ring_order_backpressure_and_payloads():
+    name = f"nvl_test_chan_{os.getpid()}"
+    tx = _Channel(name, 4096, world=3, create=True)
+    rxs = [_Channel(name, 4096, world=3, create=False) for _ in range(2)]
+    got = {1: [], 2: []}
+    N = 40
+
+    def worker(rank, rx, delay):
+        while True:
+            op, args, body = rx.recv()
+            if op == _Channel.OP_EXIT:
+                rx.ack(rank)
+                return
+            got[rank].append((op, int(args[0]), int(args[1]), bytes(body)))
+            time.sleep(delay)                               # slow consumer: rank 0 must wait, never overwrite
+            rx.ack(rank)
+
+    threads = [threading.Thread(target=worker, args=(1, rxs[0], 0.0)),
+               threading.Thread(target=worker, args=(2, rxs[1], 0.002))]
+    for t in threads:
+        t.start()
+    sent = []
+    for k in range(N):
+        payload = np.full(1 + (k * 37) % 4000, k % 251, dtype=np.uint8)
+        tx.send(_Channel.OP_DECODE if k % 2 else _Channel.OP_PREFILL, (k, k * k), payload)
+        sent.append((_Channel.OP_DECODE if k % 2 else _Channel.OP_PREFILL, k, k * k, payload.tobytes()))
+        assert tx.sent - int(tx.cur[1:3].min()) <= _Channel.SLOTS
+    tx.send(_Channel.OP_EXIT)
+    for t in threads:
+        t.join(30)
+        assert not t.is_alive()
+    assert got[1] == sent and got[2] == sent
+    for rx in rxs:
+        rx.close()
+    tx.close()
