@@ -48,8 +48,11 @@ class OracleQwen3:
 
     def allocate_cache(self, num_blocks: int, block_size: int):
         shape = (num_blocks, block_size, self.hkv, self.d)          # model_runner.py:115 (per layer)
-        self.k_cache = [torch.zeros(shape, dtype=torch.bfloat16) for _ in range(self.L)]
-        self.v_cache = [torch.zeros(shape, dtype=torch.bfloat16) for _ in range(self.L)]
+        # dtype follows the weights: bf16 as the reference (hf_config.torch_dtype); an fp32 weight dict gives the
+        # "exact arithmetic" variant used as the yardstick of the logits-error test (no intermediate rounding)
+        dt = self.lm_head.dtype
+        self.k_cache = [torch.zeros(shape, dtype=dt) for _ in range(self.L)]
+        self.v_cache = [torch.zeros(shape, dtype=dt) for _ in range(self.L)]
 
     # -- layers/attention.py:59-75 ---------------------------------------------------------------
     def _attention(self, layer: int, q, k, v, meta: Meta):

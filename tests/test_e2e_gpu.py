@@ -196,7 +196,7 @@ def test_qwen3_06b_shape_greedy_parity_vs_oracle(ckpt_06b):
     from oracle.engine import OracleEngine
     from oracle.model import OracleQwen3
     prompts = _prompts(3, 20, 300, 10000, seed=21)
-    max_tokens = [6, 4, 5]
+    max_tokens = [24, 22, 26]
     outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, enforce_eager=False, max_model_len=1024,
                                 num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True)
     cfg, w = _oracle_weights_06b("cuda")
@@ -291,6 +291,114 @@ def test_logits_close_to_oracle(tiny_ckpt):
         worst = max(worst, rel)
     print(f"logits max|diff|/absmax over {len(ours)} steps: {worst:.5f}")
     assert worst <= 2e-2
+
+
+# ---------------------------------------------------------------------------------------------
+# Real layer WIDTHS of the larger models (BASELINE configs 3-5), two layers deep: hidden 4096 / 5120, GQA groups 4
+# and 8, intermediate 12,288 / 25,600 — the projections whose K is too deep for the single-pass skinny GEMM take
+# the multi-pass / library path with the separate SiLU and add-RMSNorm kernels, which no tiny model reaches.
+def _oracle_weights(name, vocab, device="cuda"):
+    from nano_vllm_amd.weights import parameter_shapes, qwen3_config_dict, synth_tensor
+    cfg = qwen3_config_dict(name, vocab_size=vocab, max_position_embeddings=4096)
+    return cfg, {n: synth_tensor(n, s, 0, device=device).cpu() for n, s in parameter_shapes(cfg).items()}
+
+
+@pytest.mark.parametrize("name", ["qwen3-8b-2l", "qwen3-32b-2l"])
+def test_full_width_layers_greedy_parity_vs_oracle(name):
+    from nano_vllm_amd.weights import write_synthetic_checkpoint
+    from oracle.engine import OracleEngine
+    from oracle.model import OracleQwen3
+    vocab = 2048
+    path = tempfile.mkdtemp(prefix=name.replace("-", "_") + "_")
+    write_synthetic_checkpoint(path, name, with_weights=False, vocab_size=vocab, max_position_embeddings=4096)
+    prompts = _prompts(5, 8, 400, vocab, seed=23)
+    max_tokens = [10, 6, 12, 3, 9]
+    outs, rec, nblk = _run_ours(path, prompts, max_tokens, enforce_eager=False, max_model_len=1024,
+                                num_kvcache_blocks=24, max_num_seqs=8, dummy_weights=True)
+    assert [len(o["token_ids"]) for o in outs] == max_tokens
+    cfg, w = _oracle_weights(name, vocab)
+    eng = OracleEngine(OracleQwen3(cfg, w, compiled=True), nblk, 256, max_num_seqs=8)
+    eng.keep_logits = True
+    for p, m in zip(prompts, max_tokens):
+        eng.add(p, 0.0, m, True)
+    exact = total = 0
+    worst = 0.0
+    for i, r in enumerate(rec):
+        eng.step(forced_tokens=r["tokens"])
+        o = eng.trace[-1]
+        assert o["is_prefill"] == r["prefill"] and o["tables"] == r["tables"], f"step {i}: schedule differs"
+        for row, tok in enumerate(r["tokens"]):
+            gap = float(o["logits"][row].max() - o["logits"][row, tok])
+            worst = max(worst, gap)
+            exact += gap == 0.0
+            total += 1
+    print(f"{name}: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
+    assert worst <= TOL and exact >= 0.8 * total
+
+
+def test_logits_error_vs_exact_arithmetic_is_at_the_reference_floor(tiny_ckpt):
+    """SURVEY.md §8c(2) / north star "logits within 1e-3": that bar is only meaningful against EXACT arithmetic,
+    not between two bf16 pipelines (the reference's eager and compiled modes already differ by ~2e-2 * absmax).
+    Yardstick: the oracle with the same (bf16-valued) weights evaluated in fp32 end to end — no intermediate
+    rounding. Measured against it: (a) the reference-faithful bf16 oracle = the floor any bf16 implementation of
+    this model pays; (b) ours. Ours must not be worse than 1.5x the floor (+1e-3 * absmax), both are printed."""
+    from nano_vllm_amd import LLM, SamplingParams
+    from oracle.engine import OracleEngine
+    from oracle.model import OracleQwen3, load_weights
+    prompts = _prompts(4, 5, 400, 512, seed=19)
+    llm = LLM(tiny_ckpt, enforce_eager=True, max_model_len=2048, num_kvcache_blocks=16, max_num_seqs=8)
+    ours, toks = [], []
+    llm.model_runner.sampler.register_forward_pre_hook(lambda mod, args: ours.append(args[0].float().cpu()))
+    call = llm.model_runner.call
+
+    def spy(method, *args):
+        out = call(method, *args)
+        if method in ("run", "decode_end"):
+            toks.append(list(out))
+        return out
+
+    llm.model_runner.call = spy
+    llm.generate(prompts, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True), use_tqdm=False)
+    nblk = llm.config.num_kvcache_blocks
+    llm.exit()
+    cfg, w = load_weights(tiny_ckpt)
+    engines = {"bf16": OracleEngine(OracleQwen3(cfg, w, compiled=True), nblk, 256, max_num_seqs=8),
+               "exact": OracleEngine(OracleQwen3(cfg, {k: v.float() for k, v in w.items()}, compiled=True), nblk, 256,
+                                     max_num_seqs=8)}
+    for eng in engines.values():
+        eng.keep_logits = True
+        for p in prompts:
+            eng.add(p, 0.0, 6, True)
+    floor = err = 0.0
+    for mine, t in zip(ours, toks):
+        for eng in engines.values():
+            eng.step(forced_tokens=t)
+        exact = engines["exact"].trace[-1]["logits"].float()
+        ref16 = engines["bf16"].trace[-1]["logits"].float()
+        scale = float(exact.abs().max())
+        floor = max(floor, float((ref16 - exact).abs().max()) / scale)
+        err = max(err, float((mine - exact).abs().max()) / scale)
+    print(f"max|logits - exact|/absmax: reference-faithful bf16 oracle {floor:.5f} (the floor), ours {err:.5f}")
+    assert err <= 1.5 * floor + 1e-3
+
+
+def test_prompt_longer_than_the_token_budget_end_to_end(tiny_ckpt):
+    """BASELINE config 5's path through the ENGINE: one prompt longer than max_num_batched_tokens is prefilled in
+    two steps (16,384 tokens, then the rest against the paged cache), next to two short prompts, then decoded;
+    scheduling and every sampled token are judged against the oracle."""
+    g = torch.Generator().manual_seed(29)
+    prompts = [torch.randint(0, 512, (17000,), generator=g).tolist(), torch.randint(0, 512, (40,), generator=g).tolist(),
+               torch.randint(0, 512, (300,), generator=g).tolist()]
+    max_tokens = [5, 5, 5]
+    from nano_vllm_amd.weights import write_synthetic_checkpoint
+    path = tempfile.mkdtemp(prefix="qwen3tiny_long_")
+    write_synthetic_checkpoint(path, "qwen3-tiny", seed=0, vocab_size=512, max_position_embeddings=20480)
+    outs, rec, nblk = _run_ours(path, prompts, max_tokens, enforce_eager=False, max_model_len=20480,
+                                num_kvcache_blocks=80, max_num_seqs=8, max_num_batched_tokens=16384)
+    assert rec[0]["prefill"] and rec[0]["sched"] == [16384] and rec[1]["prefill"] and rec[1]["sched"][0] == 616
+    exact, total, worst = _judge(path, prompts, max_tokens, rec, nblk, max_num_seqs=8, max_num_batched_tokens=16384)
+    print(f"17k-token prompt: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
+    assert worst <= TOL and exact >= 0.9 * total
 
 
 def test_lookahead_and_microbatch_modes_reproduce_the_serial_engine(tiny_ckpt, monkeypatch):

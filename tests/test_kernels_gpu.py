@@ -333,11 +333,13 @@ def test_paged_attn_decode_fused_equals_unfused(ops, hq, hkv, lens, with_norm):
             assert not o2[i].any()
 
 
-def test_paged_attn_decode_large_batch(ops):
-    """bench-like shape: batch 256, contexts 100..2048, group size 2 (Qwen3-0.6B)."""
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (16, 2), (8, 1), (32, 8)])
+def test_paged_attn_decode_large_batch(ops, hq, hkv):
+    """bench-like shape: batch 256, contexts 100..2048; group size 2 (Qwen3-0.6B), 8 with two / one kv heads
+    (Qwen3-32B per-rank shapes at TP = 4 / 8: the matrix-core decode kernel), 4 (Qwen3-8B)."""
     gen = g(30)
     lens = torch.randint(100, 2049, (256,), generator=gen).tolist()
-    hq, hkv, bs = 16, 8, 256
+    bs = 256
     kc, vc, bt = _paged_setup(lens, hkv, bs, seed=31)
     q = torch.randn(256, hq, 128, generator=gen).to(BF16)
     ctx = torch.tensor(lens, dtype=torch.int32)
@@ -358,7 +360,7 @@ def _cu(lens):
     return torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (8, 1)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (8, 1), (32, 8), (16, 2)])
 @pytest.mark.parametrize("lens", [[1], [128], [129, 64, 300], [5, 1000, 33, 257]])
 def test_prefill_contiguous(ops, hq, hkv, lens):
     n = sum(lens)
@@ -395,7 +397,7 @@ def test_prefill_many_short_sequences(ops):
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1), (32, 8)])
 @pytest.mark.parametrize("lq_lk", [[(1, 257)], [(100, 356), (256, 256), (7, 1031)], [(300, 812), (64, 64)]])
 def test_prefill_paged_prefix(ops, hq, hkv, lq_lk):
     """Prefix-cache / chunked-prefill path: Lq < Lk, K/V from the paged cache, mask bottom-right."""
@@ -428,6 +430,61 @@ def test_prefill_softmax_rescale_branch(ops):
     o_ref = ref.flash_attn_varlen_func(q, k, v, 512, cu, 512, cu, scale, True, None)
     o = ops.attn_prefill_varlen(dev(q), dev(k), dev(v), dev(cu), dev(cu), 512, scale)
     err = (o.cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+
+
+
+def _oracle_attend_chunked(q, k, v, scale, off, chunk=1024):
+    """oracle/ops.py::_attend over query blocks (its [Hq, Lq, Lk] fp32 score tensor would not fit at 16 k): rows
+    [i0, i1) of a bottom-right aligned causal problem see keys j <= i + off."""
+    out = torch.empty_like(q)
+    for i0 in range(0, q.shape[0], chunk):
+        i1 = min(q.shape[0], i0 + chunk)
+        kend = i1 + off
+        out[i0:i1] = ref._attend(q[i0:i1], k[:kend], v[:kend], scale, i0 + off)
+    return out
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1)])
+@pytest.mark.parametrize("n", [4096, 16384])
+def test_prefill_long_sequence_vs_chunked_oracle(ops, hq, hkv, n):
+    """BASELINE config 5's kernel shape (one 16 k-token prompt per step; 8/1 heads = Qwen3-32B per rank at TP=8):
+    256 key tiles, longest-first dispatch, per-wave causal tile skipping. The oracle arithmetic (fp32 scores and
+    softmax, P rounded to bf16 before P.V — oracle/ops.py::_attend) runs on the GPU in query blocks."""
+    gen = g(70 + hq)
+    q = torch.randn(n, hq, 128, generator=gen).to(BF16).cuda()
+    k = torch.randn(n, hkv, 128, generator=gen).to(BF16).cuda()
+    v = torch.randn(n, hkv, 128, generator=gen).to(BF16).cuda()
+    cu = dev(_cu([n]))
+    scale = 128 ** -0.5
+    o = ops.attn_prefill_varlen(q, k, v, cu, cu, n, scale)
+    o_ref = _oracle_attend_chunked(q, k, v, scale, 0)
+    err = (o.float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+    # the early rows attend over few keys (large values), the late rows over 16 k (values ~ 1/sqrt(n)): judge the
+    # tail on its own scale too
+    tail = slice(n - 1024, n)
+    err_t = (o[tail].float() - o_ref[tail].float()).abs().max().item()
+    assert err_t <= 2e-2 * o_ref[tail].float().abs().max().item() + 1e-3, err_t
+
+
+@pytest.mark.parametrize("hq,hkv", [(8, 1), (16, 8)])
+def test_prefill_paged_continuation_of_a_prompt_longer_than_the_token_budget(ops, hq, hkv):
+    """scheduler.py:42-46 chunk rule at max_num_batched_tokens = 16384: a 20,000-token prompt is prefilled as
+    16,384 tokens, then 3,616 tokens whose keys are ALL 20,000 tokens read from the paged cache through the
+    block table (layers/attention.py:65-66) with the bottom-right aligned mask."""
+    bs, lk, lq = 256, 20000, 3616
+    kc, vc, bt = _paged_setup([lk], hkv, bs, seed=80)
+    gen = g(81)
+    q = torch.randn(lq, hq, 128, generator=gen).to(BF16)
+    cuq, cuk = _cu([lq]), _cu([lk])
+    scale = 128 ** -0.5
+    o = ops.attn_prefill_varlen(dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(cuq), dev(cuk),
+                                lq, scale, block_tables=dev(bt))
+    ks = ref._gather_paged(kc, bt[0], lk).cuda()
+    vs = ref._gather_paged(vc, bt[0], lk).cuda()
+    o_ref = _oracle_attend_chunked(q.cuda(), ks, vs, scale, lk - lq)
+    err = (o.float() - o_ref.float()).abs().max().item()
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
 
 
@@ -471,6 +528,29 @@ def test_sampler_distribution(ops):
     chi2 = (((counts - expected) ** 2) / expected)[keep].sum().item()
     dof = int(keep.sum()) - 1
     assert chi2 < dof + 5 * math.sqrt(2 * dof), (chi2, dof)
+
+
+def test_sampler_shards_merge_to_the_full_row_draw(ops):
+    """Vocab-parallel sampling (nvl_sample_shard + nvl_sample_merge) == nvl_sample on the concatenated row, for
+    T > 0 (same Philox stream: keyed by the GLOBAL column) and T = 0 (lowest index on ties across shards)."""
+    gen = g(55)
+    b, vocab = 37, 151936
+    logits = (torch.randn(b, vocab, generator=gen) * 3).to(BF16)
+    logits[3, 100] = logits[3, 100000] = 30.0                 # a tie between shards at T = 0: lowest index wins
+    temps = torch.tensor([0.0 if i % 3 == 0 else 0.7 for i in range(b)])
+    ws = torch.empty(ops.sample_workspace_bytes(512), dtype=torch.uint8, device="cuda")
+    full = ops.sample(dev(logits), dev(temps), seed=11, offset=3, workspace=ws).cpu()
+    for parts in (2, 4, 8):
+        per = vocab // parts
+        packed = torch.zeros(parts, 512, 2, dtype=torch.int32, device="cuda")
+        dl = dev(logits)
+        for r in range(parts):
+            shard = dl[:, r * per:(r + 1) * per].contiguous()
+            ops.sample_shard(shard, dev(temps), r * per, 11, 3, ws, packed[r])
+        out = torch.empty(b, dtype=torch.int64, device="cuda")
+        ops.sample_merge(packed, parts, b, out)
+        assert torch.equal(out.cpu(), full), parts
+    assert int(full[3]) == 100
 
 
 def test_feed_tokens(ops):

@@ -11,7 +11,9 @@ export TMPDIR=/tmp
 for w in $WHAT; do
 case $w in
 tests)
-  timeout 900 python -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log; tail -5 $OUT/pytest_gpu.log;;
+  timeout 1500 python -m pytest tests -m gpu -q -rf --durations=8 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" | tee -a $OUT/pytest_gpu.log; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.log | tail -40;;
+tptests)
+  timeout 900 python -m pytest tests/test_tp_gpu.py -m gpu -q -rf -s > $OUT/pytest_tp.log 2>&1; echo "tp pytest rc=$?" | tee -a $OUT/pytest_tp.log; tail -40 $OUT/pytest_tp.log;;
 bench)
   timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench rc=$?"; tail -c 3000 $OUT/bench.json;;
 prof)
