@@ -233,6 +233,15 @@ class ModelRunner:
                 dist.init_process_group(backend, f"tcp://127.0.0.1:{_tp_port()}", world_size=self.world_size,
                                         rank=rank, **kw)
                 self._own_pg = True
+        try:
+            self._init_rest(config, hf, rank)
+        except BaseException:
+            # do not leave a half-built tensor-parallel group behind (the next engine of this process would adopt it)
+            if self._own_pg and dist.is_initialized():
+                dist.destroy_process_group()
+            raise
+
+    def _init_rest(self, config: Config, hf, rank: int):
         from .. import tp
         tp.init(rank if self.world_size > 1 else 0, self.world_size)
         self.geo = model_geometry(hf, self.world_size)
@@ -410,7 +419,7 @@ class ModelRunner:
         if self.world_size > 1:
             # the scheduler (rank 0) must not hand out a block some rank does not have
             from .. import tp
-            n = torch.tensor([cfg.num_kvcache_blocks], dtype=torch.int64)
+            n = torch.tensor([cfg.num_kvcache_blocks], dtype=torch.int64, device="cpu")
             tp.group_all_reduce(n, op=dist.ReduceOp.MIN)
             cfg.num_kvcache_blocks = int(n.item())
         assert cfg.num_kvcache_blocks > 0, "no memory left for the KV cache"

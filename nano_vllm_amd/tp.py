@@ -88,7 +88,7 @@ def init_p2p(max_rows: int, hidden: int, device: torch.device) -> bool:
     except Exception as ex:  # noqa: BLE001 - any failure here means "no IPC on this system": fall back loudly
         c, ok, why = None, False, repr(ex)
     # every rank must take the same decision
-    flag = torch.tensor([1 if ok else 0], dtype=torch.int32)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cpu")
     group_all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
         if c is not None:
@@ -120,7 +120,7 @@ def init_p2p(max_rows: int, hidden: int, device: torch.device) -> bool:
         tol = 2e-2 * float(ref.abs().max()) + 1e-3
         good = good and bool((got.float() - ref).abs().max() <= tol) and bool((y.float() - yref).abs().max() <= 0.05)
         good = good and bool((res2.float() - s).abs().max() <= tol)
-    flag = torch.tensor([1 if good else 0], dtype=torch.int32)
+    flag = torch.tensor([1 if good else 0], dtype=torch.int32, device="cpu")
     group_all_reduce(flag, op=dist.ReduceOp.MIN)
     if int(flag.item()) == 0:
         c.close()
@@ -183,7 +183,7 @@ def all_gather_small(t: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     if _comm is not None and nbytes <= 4096 and nbytes % 16 == 0:
         return _comm.all_gather(t, out)
     if _backend == "gloo" and t.is_cuda:
-        parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(_size)]
+        parts = [torch.empty(t.shape, dtype=t.dtype, device="cpu") for _ in range(_size)]
         dist.all_gather(parts, t.cpu())
         out.copy_(torch.stack(parts).view(out.shape))
         return out

@@ -121,8 +121,8 @@ def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, cau
     v32 = v.float().permute(1, 0, 2).repeat_interleave(g, dim=0)
     s = torch.matmul(q32, k32.transpose(1, 2)) * scale            # [Hq, Lq, Lk]
     if causal_offset is not None:
-        i = torch.arange(lq).unsqueeze(1)
-        j = torch.arange(lk).unsqueeze(0)
+        i = torch.arange(lq, device=q.device).unsqueeze(1)
+        j = torch.arange(lk, device=q.device).unsqueeze(0)
         s = s.masked_fill(j > i + causal_offset, float("-inf"))
     m = s.max(dim=-1, keepdim=True).values
     e = torch.exp(s - m)
