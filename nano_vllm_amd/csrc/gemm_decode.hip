@@ -430,13 +430,19 @@ struct Plan {
   bool deep;
 };
 
-// Deep-K shapes take linear_decode_multi_kernel (several passes per workgroup); NVL_GEMM_MULTI=0 reports them as
-// not covered (the caller then keeps the library GEMM) — the A/B switch for tools/gemm_bench.py.
+// Deep-K shapes (several passes per workgroup) are reported as NOT covered unless NVL_GEMM_MULTI=1: measured on
+// MI355X (profiles/r02_gemm_deep_*.json) linear_decode_multi_kernel is correct on every Qwen3-8B / 32B shape but
+// beats hipBLASLt only on a few of them (8B qkv at M = 144: 30.9 vs 40.2 us; 32B down: 176 vs 209 us) and loses
+// on the rest (8B gate_up: 89.7 vs 56.9 us). Cause: with 32 output columns per workgroup every workgroup re-reads
+// all of x — 768 workgroups x 144 x 4096 x 2 B = 906 MB of L2 traffic for 201 MB of weights — and a wave keeps
+// only 2-3 x tiles (4-6 KiB) in flight, so the kernel runs at L2 latency, not at HBM bandwidth. The fix is a
+// different decomposition (x tile shared through LDS by waves that split N, stream-K across workgroups), not a
+// tuning of this one; until then the caller keeps the library GEMM for these shapes.
 bool multi_enabled() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("NVL_GEMM_MULTI");
-    v = (e && e[0] == '0') ? 0 : 1;
+    v = (e && e[0] == '1') ? 1 : 0;
   }
   return v == 1;
 }

@@ -1,5 +1,6 @@
 """Skinny decode-linear micro-benchmark + correctness vs an fp32 reference; prints one JSON line."""
 import json, os, sys
+os.environ.setdefault("NVL_GEMM_MULTI", "1")      # this tool measures the opt-in deep-K kernel too
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
