@@ -21,6 +21,7 @@
 // The (sequence, q-block) of a workgroup is found on device from cu_seqlens_q (prefix sum in
 // LDS + binary search), so no host-side tile list is needed.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -46,7 +47,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_tok_stride,
     int64_t v_tok_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int num_seqs, int hq,
-    int hkv, int block_size, float scale_log2e) {
+    int hkv, int block_size, float scale_log2e, int xcd_map) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // two {K: 64 x 256 B, V: 64 x 320 B} tile buffers, then the tile-lookup scratch
   int* wsum = reinterpret_cast<int*>(smem + 2 * kTileBytes);
@@ -87,8 +88,26 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
   // Longest-first dispatch: workgroups are launched in block-id order and a q-block's work grows with its
   // index (causal), so tiles are taken from the END of the list and the head index varies fastest — the
   // short tiles fill the tail instead of the 64-tile ones (measured 1.2-1.4x on 4 x 4096 / 1 x 16384).
-  if ((int)blockIdx.y >= pre[num_seqs]) return;  // grid is an upper bound
-  const int tile = pre[num_seqs] - 1 - (int)blockIdx.y;
+  // Which (q-head, tile)? The G = hq / hkv query heads of a kv group stream the SAME K/V tiles. MI355X has 8 XCDs
+  // with private L2s and hands workgroup b to XCD b % 8, so with the plain order (head fastest) the heads of a
+  // group land on G different XCDs and every one of them pulls the tiles through its own L2. xcd_map: workgroups
+  // are numbered so that the G heads of a (tile, kv-head) group occupy CONSECUTIVE slots of ONE XCD — they run
+  // side by side at the same pace and all but the first hit that XCD's L2 (cdna_hip_programming.md T1; placement
+  // only changes speed, never results).
+  int head, tile_rank;
+  if (xcd_map) {
+    const int G = hq / hkv;
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int gi = slot / G, g = slot - gi * G;
+    const int j = gi * 8 + xcd;                    // (tile, kv-head) group, longest tiles first
+    tile_rank = j / hkv;
+    head = (j - tile_rank * hkv) * G + g;
+  } else {
+    head = blockIdx.x;
+    tile_rank = blockIdx.y;
+  }
+  if (tile_rank >= pre[num_seqs]) return;  // grid is an upper bound
+  const int tile = pre[num_seqs] - 1 - tile_rank;
   int lo = 0, hi_s = num_seqs;
   while (hi_s - lo > 1) {
     const int mid = (lo + hi_s) >> 1;
@@ -98,7 +117,6 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
   // cu_seqlens / block tables, SGPR-based K/V addressing whose VGPR offsets stay live across the loop)
   const int seq = __builtin_amdgcn_readfirstlane(lo);
   const int qblk = __builtin_amdgcn_readfirstlane(tile - pre[seq]);
-  const int head = blockIdx.x;
   const int kvh = head / (hq / hkv);
 
   const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
@@ -337,8 +355,20 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   const size_t lds = (size_t)2 * kTileBytes + 4 * sizeof(int) + (size_t)(num_seqs + 1) * sizeof(int);
   const float sl2 = softmax_scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
-  NVL_REQUIRE(tiles <= 65535, "nvl_attn_prefill_varlen: too many query tiles (%lld)", (long long)tiles);
+  static int xcd_map = -1;                // NVL_PREFILL_XCD=0: plain (head, tile) grid, for A/B measurements
+  if (xcd_map < 0) {
+    const char* e = getenv("NVL_PREFILL_XCD");
+    xcd_map = (e && e[0] == '0') ? 0 : 1;
+  }
   dim3 grid((unsigned)num_q_heads, (unsigned)tiles);
+  if (xcd_map) {
+    const int64_t groups = tiles * num_kv_heads;
+    const int64_t blocks = ((groups + 7) / 8) * 8 * (num_q_heads / num_kv_heads);
+    NVL_REQUIRE(blocks < (1ll << 31), "nvl_attn_prefill_varlen: too many workgroups (%lld)", (long long)blocks);
+    grid = dim3((unsigned)blocks, 1);
+  } else {
+    NVL_REQUIRE(tiles <= 65535, "nvl_attn_prefill_varlen: too many query tiles (%lld)", (long long)tiles);
+  }
   static size_t lds_cap = 0;            // dynamic LDS above 64 KiB must be opted into per kernel
   if (lds > lds_cap) {
     const size_t want = lds < 160 * 1024 ? lds + 16 * 1024 : lds;   // headroom: num_seqs moves it by a few KiB
@@ -356,11 +386,11 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   if (paged) {
     hipLaunchKernelGGL(prefill_attn_kernel<true>, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables,
-                       bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2);
+                       bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map);
   } else {
     hipLaunchKernelGGL(prefill_attn_kernel<false>, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables,
-                       bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2);
+                       bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map);
   }
   return nvl_check_launch("nvl_attn_prefill_varlen");
 }

@@ -1,0 +1,331 @@
+// lm_head GEMM with the token sampler in its epilogue, for gfx950 (decode steps: <= 256 rows).
+// Replaces, in ONE pass over the vocabulary matrix, ParallelLMHead.forward (nano-vllm layers/embed_head.py:56-66:
+// F.linear(x, weight) -> [B, V] logits) followed by Sampler.forward (layers/sampler.py:7-12), as the reference
+// runs them back to back at engine/model_runner.py:212-218. The [B, V] logits (39 MB at B = 131, bf16) are never
+// written to or re-read from HBM: every workgroup reduces its 256 columns to one {sampling key, index} pair per
+// row, and a tiny second kernel merges the ~600 pairs per row. Same arithmetic as nvl_sample on bf16-rounded
+// logits (one-pass exponential race argmax_i l_i/T - log E_i, Philox keyed by (seed, offset, row, global column),
+// T == 0 => argmax with lowest index on ties), so it also serves a vocabulary shard (col_offset) under TP.
+//
+// Decomposition ("wide tile": the opposite of gemm_decode.hip's, because here N = 151,936 gives 594 workgroups
+// without splitting K, and x must NOT be re-read per 32 columns — that costs 1.4 GB of L2 traffic for 311 MB of
+// weights, profiles/r02_gemm_deep_lm_head_kb2.json):
+//   * workgroup = 8 waves = 256 vocabulary rows of W (NT = 2 sixteen-row MFMA tiles per wave) x ALL batch rows;
+//     the waves split N, so there is no cross-wave reduction of accumulators.
+//   * K advances in 128-wide steps. The x tile of a step ([batch, 128] bf16, 36 KiB at 144 rows) is staged ONCE per
+//     workgroup into LDS (registers -> ds_write_b128, 16-byte XOR swizzle => conflict-free ds_read_b128 B fragments)
+//     and read by all 8 waves; two LDS stages, one barrier per step.
+//   * W fragments go HBM -> VGPR with non-temporal loads through a 3-deep register ring: the loads of step s + 2
+//     are issued at the start of step s, so every wave keeps 16 KiB (the workgroup 128 KiB) of the weight stream in
+//     flight. x loads of step s + 1 are issued BEFORE them (loads retire in order: x must not queue behind HBM).
+//   * v_mfma_f32_16x16x32_bf16, A = W fragment, B = x fragment: lane (m = lane & 15, q = lane >> 4) ends up with 4
+//     consecutive vocabulary columns of batch row m — exactly one Philox4x32 draw.
+//   * more than 144 rows: 16 row tiles x NT = 1 (128 columns per workgroup) keeps the accumulators in registers
+//     and the matrix streamed once.
+#include "common.h"
+#include <math.h>
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+constexpr int kNW = 8;
+constexpr int kBK = 128;                 // k per step
+constexpr int kKB = kBK / 32;            // 32-wide MFMA k blocks per step
+
+__host__ __device__ __forceinline__ float u01_bits(uint32_t x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }
+
+struct Best {
+  float v;
+  int idx;
+};
+__device__ __forceinline__ Best better(Best a, Best b) {
+  if (b.v > a.v || (b.v == a.v && b.idx < a.idx)) return b;
+  return a;
+}
+
+template <int MT, int NT>
+__global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
+    const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ temps,
+    uint32_t* __restrict__ partial, bf16_t* __restrict__ logits_out, int M, int V, int K, int64_t col_offset,
+    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+  constexpr int kRows = MT * 16;
+  constexpr int kStage = kRows * 256;                       // bytes per LDS stage
+  constexpr int kCH = (kRows * 16 + kNW * 64 - 1) / (kNW * 64);   // 16-byte x chunks per thread per step
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int steps = K / kBK;
+  const int n0 = (blockIdx.x * kNW + wave) * (NT * 16);     // this wave's first (local) vocabulary column
+
+  const bf16_t* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int row = n0 + nt * 16 + l15;
+    row = row < V ? row : V - 1;                            // ragged last workgroup: any valid row, masked below
+    wrow[nt] = w + (int64_t)row * K + lq * 8;
+  }
+  // x staging: chunk c = tid + i * 512 -> row c >> 4, 16-byte column c & 15
+  int x_src[kCH], x_dst[kCH];
+#pragma unroll
+  for (int i = 0; i < kCH; ++i) {
+    const int c = tid + i * (kNW * 64);
+    int row = c >> 4;
+    const int col = c & 15;
+    x_dst[i] = row < kRows ? row * 256 + ((col ^ (row & 15)) << 4) : -1;
+    row = row < M ? row : M - 1;                            // padding rows read a valid row (never reported)
+    x_src[i] = row * K + col * 8;
+  }
+  int frag_off[kKB];                                        // B fragment of k block kb: row l15 of a row tile
+#pragma unroll
+  for (int kb = 0; kb < kKB; ++kb) frag_off[kb] = l15 * 256 + (((kb * 4 + lq) ^ l15) << 4);
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t wf[3][NT][kKB];
+  u32x4_t xr[kCH];
+  auto wload = [&](u32x4_t (*dst)[kKB], int s) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int kb = 0; kb < kKB; ++kb)
+        dst[nt][kb] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[nt] + s * kBK + kb * 32));
+  };
+  auto xload = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < kCH; ++i) xr[i] = *reinterpret_cast<const u32x4_t*>(x + x_src[i] + s * kBK);
+  };
+  auto xwrite = [&](int stage) {
+#pragma unroll
+    for (int i = 0; i < kCH; ++i)
+      if (x_dst[i] >= 0) *reinterpret_cast<u32x4_t*>(smem + stage * kStage + x_dst[i]) = xr[i];
+  };
+
+  // prologue: x(0) -> LDS stage 0; W(0), W(1) in flight
+  xload(0);
+  wload(wf[0], 0);
+  if (steps > 1) wload(wf[1], 1);
+  __builtin_amdgcn_sched_barrier(0);
+  xwrite(0);
+  __syncthreads();
+
+  auto step = [&](auto idx_tag, int s) {
+    constexpr int IDX = decltype(idx_tag)::value;           // s mod 6: register-ring slot and LDS stage are static
+    constexpr int SET = IDX % 3, STAGE = IDX & 1;
+    // next step's x first (L2), THEN the weights two steps ahead (HBM): loads retire in order
+    if (s + 1 < steps) xload(s + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 2 < steps) wload(wf[(SET + 2) % 3], s + 2);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned char* xs = smem + STAGE * kStage;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      u32x4_t f[kKB];
+#pragma unroll
+      for (int kb = 0; kb < kKB; ++kb) f[kb] = *reinterpret_cast<const u32x4_t*>(xs + mt * 16 * 256 + frag_off[kb]);
+#pragma unroll
+      for (int kb = 0; kb < kKB; ++kb)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[SET][nt][kb]),
+                                                                __builtin_bit_cast(bf16x8_t, f[kb]), acc[mt][nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < steps) xwrite(STAGE ^ 1);                   // that stage was last read one barrier ago
+    __syncthreads();
+  };
+  for (int s = 0; s < steps; s += 6) {
+    step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < steps) step(std::integral_constant<int, 1>{}, s + 1);
+    if (s + 2 < steps) step(std::integral_constant<int, 2>{}, s + 2);
+    if (s + 3 < steps) step(std::integral_constant<int, 3>{}, s + 3);
+    if (s + 4 < steps) step(std::integral_constant<int, 4>{}, s + 4);
+    if (s + 5 < steps) step(std::integral_constant<int, 5>{}, s + 5);
+  }
+
+  // ---- epilogue: bf16-round the logits, (optionally store them,) reduce each row's sampling key ---------------
+  const uint64_t off = offset + (offset_dev ? *offset_dev : 0ull);
+  const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+  Best* red = reinterpret_cast<Best*>(smem);                // [kNW][kRows] (the x stages are dead: barrier above)
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 16 + l15;
+    const bool row_ok = m < M;
+    const float T = row_ok ? temps[m] : 0.f;
+    const bool greedy = !(T > 0.f);
+    const float invT = greedy ? 1.f : 1.f / T;
+    Best best{-INFINITY, 0x7fffffff};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int col0 = n0 + nt * 16 + lq * 4;               // local column of element 0 of this lane's quad
+      const int64_t gcol0 = col_offset + col0;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = round_bf16(acc[mt][nt][r]);
+      if (logits_out != nullptr && row_ok && col0 + 3 < V) {
+        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2_t*>(logits_out + (int64_t)m * V + col0) = o;
+      } else if (logits_out != nullptr && row_ok) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (col0 + r < V) logits_out[(int64_t)m * V + col0 + r] = (bf16_t)v[r];
+      }
+      float key[4];
+      if (__all(greedy)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) key[r] = v[r];
+      } else {
+        const int64_t ctr = gcol0 >> 2;                      // the draw nvl_sample makes for these 4 columns
+        const Philox4 rnd = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32) ^ (uint32_t)(off << 8), (uint32_t)m,
+                                          (uint32_t)(off >> 24), k0, k1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float e = -__logf(u01_bits(rnd.v[r]));
+          e = e < 1e-10f ? 1e-10f : e;
+          key[r] = greedy ? v[r] : v[r] * invT - __logf(e);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (col0 + r < V) best = better(best, Best{key[r], (int)(gcol0 + r)});
+    }
+    // the 4 lanes l15, l15 + 16, + 32, + 48 hold the same row
+    Best o1{__shfl_xor(best.v, 16, 64), __shfl_xor(best.idx, 16, 64)};
+    best = better(best, o1);
+    Best o2{__shfl_xor(best.v, 32, 64), __shfl_xor(best.idx, 32, 64)};
+    best = better(best, o2);
+    if (lq == 0) red[wave * kRows + m] = best;
+  }
+  __syncthreads();
+  if (tid < kRows && tid < M) {
+    Best b = red[tid];
+#pragma unroll
+    for (int ww = 1; ww < kNW; ++ww) b = better(b, red[ww * kRows + tid]);
+    uint32_t* dst = partial + ((int64_t)blockIdx.x * M + tid) * 2;
+    dst[0] = __float_as_uint(b.v);
+    dst[1] = (uint32_t)b.idx;
+  }
+}
+
+// One workgroup per batch row: merge `parts` packed {key bits, index} pairs (part p of row r at
+// packed[(p * batch + r) * 2]) into the winning index (int64) and/or the packed winner of this shard.
+__global__ __launch_bounds__(256) void lmhead_merge_kernel(const uint32_t* __restrict__ packed, int parts, int batch,
+                                                            int64_t* __restrict__ out, uint32_t* __restrict__ out_packed) {
+  __shared__ float sv[4];
+  __shared__ int si[4];
+  const int row = blockIdx.x;
+  Best b{-INFINITY, 0x7fffffff};
+  for (int p = threadIdx.x; p < parts; p += 256) {
+    const uint32_t* q = packed + ((int64_t)p * batch + row) * 2;
+    b = better(b, Best{__uint_as_float(q[0]), (int)q[1]});
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    Best other{__shfl_xor(b.v, o, 64), __shfl_xor(b.idx, o, 64)};
+    b = better(b, other);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    sv[threadIdx.x >> 6] = b.v;
+    si[threadIdx.x >> 6] = b.idx;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    Best r{sv[0], si[0]};
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) r = better(r, Best{sv[ww], si[ww]});
+    if (out) out[row] = r.idx == 0x7fffffff ? 0 : (int64_t)r.idx;
+    if (out_packed) {
+      out_packed[row * 2] = __float_as_uint(r.v);
+      out_packed[row * 2 + 1] = (uint32_t)r.idx;
+    }
+  }
+}
+
+struct LmPlan {
+  int mt, nt, groups;
+};
+
+bool lm_plan(int64_t batch, int64_t vocab, int k, LmPlan* p) {
+  if (batch < 1 || batch > 256 || vocab < 16 || k < kBK || k % kBK) return false;
+  const int mtiles = (int)((batch + 15) / 16);
+  static const int kMT2[] = {1, 2, 3, 5, 7, 9};
+  p->mt = 0;
+  for (int c : kMT2)
+    if (c >= mtiles) { p->mt = c; p->nt = 2; break; }
+  if (!p->mt) { p->mt = mtiles <= 12 ? 12 : 16; p->nt = 1; }
+  const int cols = kNW * p->nt * 16;
+  p->groups = (int)((vocab + cols - 1) / cols);
+  return true;
+}
+
+template <int MT, int NT>
+int launch_lm(const LmPlan& p, const void* x, const void* w, const float* temps, uint32_t* partial, void* logits,
+              int64_t batch, int64_t vocab, int k, int64_t col_offset, uint64_t seed, uint64_t offset,
+              const uint64_t* offset_dev, hipStream_t s) {
+  const size_t lds_x = (size_t)2 * MT * 16 * 256;
+  const size_t lds_red = (size_t)kNW * MT * 16 * sizeof(Best);
+  const size_t lds = lds_x > lds_red ? lds_x : lds_red;
+  static bool attr_set = false;
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lmhead_sample_kernel<MT, NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      nvl_set_error("nvl_lmhead_sample: cannot reserve %zu B of LDS", lds);
+      return NVL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((lmhead_sample_kernel<MT, NT>), dim3((unsigned)p.groups), dim3(kNW * 64), lds, s,
+                     (const bf16_t*)x, (const bf16_t*)w, temps, partial, (bf16_t*)logits, (int)batch, (int)vocab, k,
+                     col_offset, seed, offset, offset_dev);
+  return NVL_OK;
+}
+
+}  // namespace
+
+extern "C" size_t nvl_lmhead_sample_workspace_bytes(int64_t batch, int64_t vocab_local, int k) {
+  LmPlan p;
+  if (!lm_plan(batch, vocab_local, k, &p)) return 0;         // 0 = shape not covered: keep GEMM + nvl_sample
+  return (size_t)p.groups * batch * 2 * sizeof(uint32_t);
+}
+
+extern "C" int nvl_lmhead_sample(const void* x, const void* weight, const float* temperatures, int64_t* out,
+                                 void* best_packed, void* logits_out, int64_t batch, int64_t vocab_local, int k,
+                                 int64_t col_offset, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  NVL_REQUIRE(x && weight && temperatures && workspace && (out || best_packed), "nvl_lmhead_sample: null pointer");
+  NVL_REQUIRE(((uintptr_t)x | (uintptr_t)weight | (uintptr_t)workspace | (uintptr_t)logits_out | (uintptr_t)best_packed) % 8 == 0 &&
+                  ((uintptr_t)x | (uintptr_t)weight) % 16 == 0,
+              "nvl_lmhead_sample: x / weight must be 16-byte aligned (others 8)");
+  NVL_REQUIRE(col_offset >= 0 && col_offset % 8 == 0 && col_offset + vocab_local < (1ll << 31) - 8,
+              "nvl_lmhead_sample: bad col_offset=%lld", (long long)col_offset);
+  LmPlan p;
+  if (!lm_plan(batch, vocab_local, k, &p)) {
+    nvl_set_error("nvl_lmhead_sample: shape batch=%lld vocab=%lld k=%d not covered (batch <= 256, k %% 128 == 0)",
+                  (long long)batch, (long long)vocab_local, k);
+    return NVL_EUNSUPPORTED;
+  }
+  NVL_REQUIRE(workspace_bytes >= (size_t)p.groups * batch * 8, "nvl_lmhead_sample: workspace too small");
+  NVL_REQUIRE(logits_out == nullptr || vocab_local % 4 == 0, "nvl_lmhead_sample: logits_out needs vocab %% 4 == 0");
+  hipStream_t s = (hipStream_t)stream;
+  uint32_t* partial = (uint32_t*)workspace;
+  int rc = NVL_EINVAL;
+#define NVL_LM_CASE(MT_, NT_)                                                                                   \
+  if (p.mt == MT_ && p.nt == NT_)                                                                               \
+    rc = launch_lm<MT_, NT_>(p, x, weight, temperatures, partial, logits_out, batch, vocab_local, k, col_offset, \
+                             seed, offset, offset_dev, s);
+  NVL_LM_CASE(1, 2) NVL_LM_CASE(2, 2) NVL_LM_CASE(3, 2) NVL_LM_CASE(5, 2) NVL_LM_CASE(7, 2) NVL_LM_CASE(9, 2)
+  NVL_LM_CASE(12, 1) NVL_LM_CASE(16, 1)
+#undef NVL_LM_CASE
+  if (rc != NVL_OK) {
+    if (rc == NVL_EINVAL) nvl_set_error("nvl_lmhead_sample: internal plan error (mt=%d nt=%d)", p.mt, p.nt);
+    return rc;
+  }
+  hipLaunchKernelGGL(lmhead_merge_kernel, dim3((unsigned)batch), dim3(256), 0, s, partial, p.groups, (int)batch, out,
+                     (uint32_t*)best_packed);
+  return nvl_check_launch("nvl_lmhead_sample");
+}
