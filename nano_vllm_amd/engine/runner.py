@@ -35,7 +35,7 @@ import torch.distributed as dist
 
 from .. import ops
 from ..api import Config, model_geometry
-from ..attn_meta import reset_context, set_context
+from ..attn_meta import get_context, reset_context, set_context
 from ..layers import Sampler
 from ..qwen3 import Qwen3ForCausalLM
 from ..weights import init_dummy_weights, load_model
@@ -531,11 +531,19 @@ class ModelRunner:
     def _sample(self, hidden, temps, out, rng, sampler):
         """lm_head + sampler on the current stream; TP > 1: every rank samples its vocabulary shard and the
         per-row winners are merged on every rank (no [B, V] gather, embed_head.py:62-65)."""
+        col0 = self.rank * self.geo["vocab_per_rank"]
+        ctx = get_context()
+        rows = hidden
+        if ctx.is_prefill:                                   # only each sequence's last token is sampled
+            rows = hidden[(ctx.cu_seqlens_q[1:] - 1).long()].contiguous()
+        # one pass over the vocabulary matrix, logits never in HBM (nvl_lmhead_sample); None = shape not covered
+        if sampler.forward_lm_head(rows, self.model.lm_head.weight, temps, out, col0, offset_dev=rng) is not None:
+            return
         if self.world_size == 1:
             sampler(self.model.compute_logits(hidden), temps, out=out, offset_dev=rng)
         else:
             logits = self.model.compute_logits_shard(hidden)
-            sampler.forward_shard(logits, temps, self.rank * self.geo["vocab_per_rank"], out, offset_dev=rng)
+            sampler.forward_shard(logits, temps, col0, out, offset_dev=rng)
 
     def _decode_rows(self, r0: int, r1: int, ws, sampler):
         """Decode forward for rows [r0, r1) of the static device buffers, on the current stream."""

@@ -102,6 +102,8 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, de
 
 # NVL_FUSED_DECODE=0 keeps the separate q/k-norm+RoPE+KV-store launch on decode steps (A/B measurements)
 _FUSED_DECODE = os.environ.get("NVL_FUSED_DECODE", "1") != "0"
+# NVL_FUSED_LMHEAD=0 keeps lm_head GEMM (hipBLASLt) + nvl_sample as two steps with the logits in HBM
+_FUSED_LMHEAD = os.environ.get("NVL_FUSED_LMHEAD", "1") != "0"
 
 
 class Attention(nn.Module):
@@ -171,6 +173,8 @@ class Sampler(nn.Module):
         self.seed = seed
         self.calls = 0
         self._ws = None
+        self._lm_ws = None
+        self.capture: list | None = None        # tests: every step's logits (fp32, host) are appended here
 
     def forward(self, logits: torch.Tensor, temperatures: torch.Tensor, out: torch.Tensor | None = None,
                 offset_dev: torch.Tensor | None = None) -> torch.Tensor:
@@ -182,7 +186,52 @@ class Sampler(nn.Module):
             logits = logits.to(torch.bfloat16)
         offset = 0 if offset_dev is not None else self.calls
         self.calls += 1
+        if self.capture is not None:
+            self.capture.append(logits.float().cpu())
         return ops.sample(logits, temperatures, self.seed, offset, self._ws, out=out, offset_dev=offset_dev)
+
+    def forward_lm_head(self, hidden: torch.Tensor, weight: torch.Tensor, temperatures: torch.Tensor, out: torch.Tensor,
+                        col_offset: int = 0, offset_dev: torch.Tensor | None = None) -> torch.Tensor | None:
+        """lm_head GEMM + sampling in one pass (nvl_lmhead_sample): `hidden` [B, K] are the rows to sample from,
+        `weight` this rank's [V/tp, K] lm_head shard. Returns None when the shape is not covered (B > 256): the
+        caller then runs the GEMM and `forward` / `forward_shard`. TP > 1: the shard winners are exchanged and
+        merged as in `forward_shard`."""
+        b, k = hidden.shape
+        v = weight.shape[0]
+        if not (_FUSED_LMHEAD and hidden.is_cuda and hidden.dtype == torch.bfloat16 and hidden.is_contiguous()):
+            return None
+        need = ops.lmhead_sample_workspace_bytes(b, v, k)
+        if need == 0:
+            return None
+        # sized ONCE for the largest covered batch of either tiling: captured graphs keep pointing at it
+        need = max(ops.lmhead_sample_workspace_bytes(144, v, k), ops.lmhead_sample_workspace_bytes(256, v, k))
+        if self._lm_ws is None or self._lm_ws.numel() < need or self._lm_ws.device != hidden.device:
+            self._lm_ws = torch.empty(need, dtype=torch.uint8, device=hidden.device)
+        offset = 0 if offset_dev is not None else self.calls
+        self.calls += 1
+        logits = None
+        if self.capture is not None:
+            logits = torch.empty((b, v), dtype=torch.bfloat16, device=hidden.device)
+        _, size = tp.world()
+        if size == 1:
+            ops.lmhead_sample(hidden, weight, temperatures, self.seed, offset, self._lm_ws, out=out, logits_out=logits,
+                              offset_dev=offset_dev)
+        else:
+            self._pair_buffers(b, size, hidden.device)
+            ops.lmhead_sample(hidden, weight, temperatures, self.seed, offset, self._lm_ws, out_packed=self._mine,
+                              logits_out=logits, col_offset=col_offset, offset_dev=offset_dev)
+            tp.all_gather_small(self._mine, self._pairs)
+            ops.sample_merge(self._pairs, size, b, out)
+        if logits is not None:
+            self.capture.append(logits.float().cpu())
+        return out
+
+    def _pair_buffers(self, b: int, size: int, device) -> None:
+        if getattr(self, "_pairs", None) is None or self._pairs.shape[1] < b or self._pairs.device != device:
+            rows = max(b, 512)
+            # whole fixed-size buffers travel (4 KiB at 512 rows): shape-independent => graph-safe
+            self._mine = torch.zeros((rows, 2), dtype=torch.int32, device=device)
+            self._pairs = torch.zeros((size, rows, 2), dtype=torch.int32, device=device)
 
     def forward_shard(self, logits: torch.Tensor, temperatures: torch.Tensor, col_offset: int, out: torch.Tensor,
                       offset_dev: torch.Tensor | None = None) -> torch.Tensor:
@@ -195,14 +244,11 @@ class Sampler(nn.Module):
         need = ops.sample_workspace_bytes(max(b, 512))
         if self._ws is None or self._ws.numel() < need or self._ws.device != logits.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=logits.device)
-        if getattr(self, "_pairs", None) is None or self._pairs.shape[1] < b or self._pairs.device != logits.device:
-            rows = max(b, 512)
-            self._mine = torch.zeros((rows, 2), dtype=torch.int32, device=logits.device)
-            self._pairs = torch.zeros((size, rows, 2), dtype=torch.int32, device=logits.device)
+        self._pair_buffers(b, size, logits.device)
         offset = 0 if offset_dev is not None else self.calls
         self.calls += 1
-        rows = self._mine.shape[0]
-        # whole fixed-size buffers travel (4 KiB at 512 rows): shape-independent => graph-safe
+        if self.capture is not None:
+            self.capture.append(logits.float().cpu())
         ops.sample_shard(logits, temperatures, col_offset, self.seed, offset, self._ws, self._mine, offset_dev=offset_dev)
         tp.all_gather_small(self._mine, self._pairs)
         return ops.sample_merge(self._pairs, size, b, out)

@@ -262,8 +262,7 @@ def test_logits_close_to_oracle(tiny_ckpt):
     prompts = _prompts(4, 5, 400, 512, seed=17)
     llm = LLM(tiny_ckpt, enforce_eager=True, max_model_len=2048, num_kvcache_blocks=16, max_num_seqs=8)
     ours, toks = [], []
-    for smp in (llm.model_runner.sampler,):
-        smp.register_forward_pre_hook(lambda mod, args: ours.append(args[0].float().cpu()))
+    llm.model_runner.sampler.capture = ours            # every step's logits, whichever sampling path runs
     call = llm.model_runner.call
 
     def spy(method, *args):
@@ -348,7 +347,7 @@ def test_logits_error_vs_exact_arithmetic_is_at_the_reference_floor(tiny_ckpt):
     prompts = _prompts(4, 5, 400, 512, seed=19)
     llm = LLM(tiny_ckpt, enforce_eager=True, max_model_len=2048, num_kvcache_blocks=16, max_num_seqs=8)
     ours, toks = [], []
-    llm.model_runner.sampler.register_forward_pre_hook(lambda mod, args: ours.append(args[0].float().cpu()))
+    llm.model_runner.sampler.capture = ours
     call = llm.model_runner.call
 
     def spy(method, *args):

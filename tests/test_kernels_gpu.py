@@ -553,6 +553,43 @@ def test_sampler_shards_merge_to_the_full_row_draw(ops):
     assert int(full[3]) == 100
 
 
+@pytest.mark.parametrize("b", [1, 16, 17, 131, 144, 145, 200, 256])
+@pytest.mark.parametrize("v,k", [(151936, 1024), (4104, 384), (2048, 4096)])
+def test_lmhead_sample_fused_equals_gemm_then_sample(ops, b, v, k):
+    """nvl_lmhead_sample (logits never in HBM) vs the two-step path on ITS OWN rounded logits: the stored logits
+    must be the bf16-rounded fp32 product (GEMM-class tolerance), and the sampled ids must equal nvl_sample run on
+    those stored logits exactly (same keys, same Philox draw, same tie rule) — T > 0 and T = 0 rows mixed, ragged
+    last column group (4104 = 16 * 256 + 8), both tilings (b <= 144: 256 columns per workgroup, else 128)."""
+    gen = g(90 + b)
+    x = (torch.randn(b, k, generator=gen) * 0.5).to(BF16)
+    w = (torch.randn(v, k, generator=gen) * 0.05).to(BF16)
+    temps = torch.tensor([0.0 if i % 4 == 1 else 0.5 + 0.1 * (i % 7) for i in range(b)])
+    need = ops.lmhead_sample_workspace_bytes(b, v, k)
+    assert need > 0
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    logits = torch.empty(b, v, dtype=BF16, device="cuda")
+    out = torch.empty(b, dtype=torch.int64, device="cuda")
+    ops.lmhead_sample(dev(x), dev(w), dev(temps), seed=21, offset=9, workspace=ws, out=out, logits_out=logits)
+    acc = dev(x).float() @ dev(w).float().t()
+    assert _close_to_rounded(logits.cpu(), acc.cpu(), atol=1e-4)
+    ws2 = torch.empty(ops.sample_workspace_bytes(512), dtype=torch.uint8, device="cuda")
+    want = ops.sample(logits, dev(temps), seed=21, offset=9, workspace=ws2)
+    assert torch.equal(out.cpu(), want.cpu())
+    # without logits_out the result is the same, and a shard (col_offset) merges to the same winner
+    out2 = torch.empty_like(out)
+    ops.lmhead_sample(dev(x), dev(w), dev(temps), seed=21, offset=9, workspace=ws, out=out2)
+    assert torch.equal(out2.cpu(), want.cpu())
+    if v % 16 == 0:
+        half = v // 2
+        packed = torch.zeros(2, 512, 2, dtype=torch.int32, device="cuda")
+        for r in range(2):
+            ops.lmhead_sample(dev(x), dev(w)[r * half:(r + 1) * half].contiguous(), dev(temps), seed=21, offset=9,
+                              workspace=ws, out_packed=packed[r], col_offset=r * half)
+        out3 = torch.empty_like(out)
+        ops.sample_merge(packed, 2, b, out3)
+        assert torch.equal(out3.cpu(), want.cpu())
+
+
 def test_feed_tokens(ops):
     """nvl_feed_tokens: ids[i] = prev[src[i]] where src[i] >= 0, untouched elsewhere (bit-exact index work)."""
     gen = g(50)

@@ -36,6 +36,12 @@ gemmx)
   done;;
 retest)
   timeout 1200 python -m pytest tests/test_tp_gpu.py tests/test_kernels_gpu.py -m gpu -q -rf -k "tp2 or long or continuation or shards or linear_decode or p2p" > $OUT/pytest_retest.log 2>&1; echo "retest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_retest.log | tail -20;;
+lmhead)
+  timeout 600 python tools/lmhead_bench.py > $OUT/lmhead_bench.json 2> $OUT/lmhead_bench.err; echo "lmhead rc=$?"; tail -c 600 $OUT/lmhead_bench.err; cat $OUT/lmhead_bench.json;;
+prefillx)
+  for x in 0 1; do NVL_PREFILL_XCD=$x timeout 600 python tools/prefill_bench.py > $OUT/prefill_xcd$x.json 2> $OUT/prefill_xcd$x.err; echo "prefill xcd=$x rc=$?"; cat $OUT/prefill_xcd$x.json; echo; done;;
+newtests)
+  timeout 1200 python -m pytest tests -m gpu -q -rf -k "lmhead or prefill or logits or tiny_model_greedy or tp2 or sampler or 06b_shape_greedy" > $OUT/pytest_new.log 2>&1; echo "newtests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_new.log | tail -20;;
 replay)
   timeout 600 python tools/attn_replay.py --fused > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
 *) echo "unknown step $w";;
