@@ -271,7 +271,7 @@ int nvl_sample_merge(const void* best_packed, int parts, int64_t part_stride_byt
  * workgroup reduces its vocabulary columns to one {key, index} pair per row in the GEMM epilogue
  * and a second small kernel merges them. Same arithmetic and the same Philox draw as nvl_sample /
  * nvl_sample_shard on bf16-rounded logits (col_offset = global index of local column 0).
- *   x [batch, k] bf16 contiguous (batch <= 256); weight [vocab_local, k] bf16 contiguous.
+ *   x [batch, k] bf16 contiguous (batch <= 192); weight [vocab_local, k] bf16 contiguous.
  *   out (int64 [batch]) and/or best_packed ([batch][2] words, the shard's winner for
  *   nvl_sample_merge) — at least one; logits_out (optional, bf16 [batch, vocab_local]) also
  *   stores the rounded logits (tests / logit consumers).

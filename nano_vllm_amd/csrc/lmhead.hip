@@ -20,8 +20,8 @@
 //     flight. x loads of step s + 1 are issued BEFORE them (loads retire in order: x must not queue behind HBM).
 //   * v_mfma_f32_16x16x32_bf16, A = W fragment, B = x fragment: lane (m = lane & 15, q = lane >> 4) ends up with 4
 //     consecutive vocabulary columns of batch row m — exactly one Philox4x32 draw.
-//   * more than 144 rows: 16 row tiles x NT = 1 (128 columns per workgroup) keeps the accumulators in registers
-//     and the matrix streamed once.
+//   * 145-192 rows: 12 row tiles x NT = 1 (128 columns per workgroup) keeps the accumulators in registers and the
+//     matrix streamed once; above 192 rows the caller keeps GEMM + nvl_sample (16 row tiles spill).
 #include "common.h"
 #include <math.h>
 #include <stdlib.h>
@@ -44,7 +44,7 @@ __device__ __forceinline__ Best better(Best a, Best b) {
   return a;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int SB>
 __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ temps,
     uint32_t* __restrict__ partial, bf16_t* __restrict__ logits_out, int M, int V, int K, int64_t col_offset,
@@ -87,7 +87,10 @@ __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-  u32x4_t wf[3][NT][kKB];
+  // ring depth: 3 sets (two steps ahead) while the accumulators leave room, 2 sets (one step ahead: still 64 KiB of
+  // weights in flight per workgroup) for the 9 x 2 and 16 x 1 tilings, which would spill otherwise
+  constexpr int RING = (MT * NT > 12) ? 2 : 3;
+  u32x4_t wf[RING][NT][kKB];
   u32x4_t xr[kCH];
   auto wload = [&](u32x4_t (*dst)[kKB], int s) {
 #pragma unroll
@@ -106,46 +109,44 @@ __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
       if (x_dst[i] >= 0) *reinterpret_cast<u32x4_t*>(smem + stage * kStage + x_dst[i]) = xr[i];
   };
 
-  // prologue: x(0) -> LDS stage 0; W(0), W(1) in flight
-  xload(0);
-  wload(wf[0], 0);
-  if (steps > 1) wload(wf[1], 1);
-  __builtin_amdgcn_sched_barrier(0);
-  xwrite(0);
-  __syncthreads();
-
-  auto step = [&](auto idx_tag, int s) {
-    constexpr int IDX = decltype(idx_tag)::value;           // s mod 6: register-ring slot and LDS stage are static
-    constexpr int SET = IDX % 3, STAGE = IDX & 1;
-    // next step's x first (L2), THEN the weights two steps ahead (HBM): loads retire in order
-    if (s + 1 < steps) xload(s + 1);
+  // K is walked in blocks of SB steps whose code is STRAIGHT-LINE (fully unrolled, compile-time guards): hipcc's
+  // s_waitcnt insertion is exact in straight-line code, whereas at loop headers / branch joins it merges the
+  // outstanding-load scoreboards conservatively and ends up waiting vmcnt(0..5) before every use — which silently
+  // turns a 3-deep prefetch ring into a synchronous load (seen in the .s of the first version of this kernel:
+  // 154 us instead of ~65 for the Qwen3-0.6B head at 131 rows). The ring drains at a block boundary (one HBM round
+  // trip per SB steps; Qwen3-0.6B is a single block).
+  for (int blk = 0; blk < steps / SB; ++blk) {
+    const int s0 = blk * SB;
+    xload(s0);
+    wload(wf[0], s0);
+    if constexpr (SB > 1 && RING > 2) wload(wf[1], s0 + 1);
     __builtin_amdgcn_sched_barrier(0);
-    if (s + 2 < steps) wload(wf[(SET + 2) % 3], s + 2);
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned char* xs = smem + STAGE * kStage;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      u32x4_t f[kKB];
-#pragma unroll
-      for (int kb = 0; kb < kKB; ++kb) f[kb] = *reinterpret_cast<const u32x4_t*>(xs + mt * 16 * 256 + frag_off[kb]);
-#pragma unroll
-      for (int kb = 0; kb < kKB; ++kb)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[SET][nt][kb]),
-                                                                __builtin_bit_cast(bf16x8_t, f[kb]), acc[mt][nt], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (s + 1 < steps) xwrite(STAGE ^ 1);                   // that stage was last read one barrier ago
+    xwrite(0);
     __syncthreads();
-  };
-  for (int s = 0; s < steps; s += 6) {
-    step(std::integral_constant<int, 0>{}, s);
-    if (s + 1 < steps) step(std::integral_constant<int, 1>{}, s + 1);
-    if (s + 2 < steps) step(std::integral_constant<int, 2>{}, s + 2);
-    if (s + 3 < steps) step(std::integral_constant<int, 3>{}, s + 3);
-    if (s + 4 < steps) step(std::integral_constant<int, 4>{}, s + 4);
-    if (s + 5 < steps) step(std::integral_constant<int, 5>{}, s + 5);
+#pragma unroll
+    for (int i = 0; i < SB; ++i) {
+      // next step's x first (L2), THEN the weights two steps ahead (HBM): loads retire in order
+      if (i + 1 < SB) xload(s0 + i + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + RING - 1 < SB) wload(wf[(i + RING - 1) % RING], s0 + i + RING - 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* xs = smem + (i & 1) * kStage;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        u32x4_t f[kKB];
+#pragma unroll
+        for (int kb = 0; kb < kKB; ++kb) f[kb] = *reinterpret_cast<const u32x4_t*>(xs + mt * 16 * 256 + frag_off[kb]);
+#pragma unroll
+        for (int kb = 0; kb < kKB; ++kb)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i % RING][nt][kb]),
+                                                                  __builtin_bit_cast(bf16x8_t, f[kb]), acc[mt][nt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i + 1 < SB) xwrite((i + 1) & 1);                  // that stage was last read one barrier ago
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: bf16-round the logits, (optionally store them,) reduce each row's sampling key ---------------
@@ -247,23 +248,26 @@ __global__ __launch_bounds__(256) void lmhead_merge_kernel(const uint32_t* __res
 }
 
 struct LmPlan {
-  int mt, nt, groups;
+  int mt, nt, groups, sb;
 };
 
 bool lm_plan(int64_t batch, int64_t vocab, int k, LmPlan* p) {
-  if (batch < 1 || batch > 256 || vocab < 16 || k < kBK || k % kBK) return false;
+  if (batch < 1 || batch > 192 || vocab < 16 || k < kBK || k % kBK) return false;   // 16 row tiles spill: not built
+  const int steps = k / kBK;
+  p->sb = steps % 8 == 0 ? 8 : (steps % 5 == 0 ? 5 : (steps % 3 == 0 ? 3 : 0));     // straight-line block length
+  if (!p->sb) return false;
   const int mtiles = (int)((batch + 15) / 16);
   static const int kMT2[] = {1, 2, 3, 5, 7, 9};
   p->mt = 0;
   for (int c : kMT2)
     if (c >= mtiles) { p->mt = c; p->nt = 2; break; }
-  if (!p->mt) { p->mt = mtiles <= 12 ? 12 : 16; p->nt = 1; }
+  if (!p->mt) { p->mt = 12; p->nt = 1; }
   const int cols = kNW * p->nt * 16;
   p->groups = (int)((vocab + cols - 1) / cols);
   return true;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int SB>
 int launch_lm(const LmPlan& p, const void* x, const void* w, const float* temps, uint32_t* partial, void* logits,
               int64_t batch, int64_t vocab, int k, int64_t col_offset, uint64_t seed, uint64_t offset,
               const uint64_t* offset_dev, hipStream_t s) {
@@ -272,14 +276,14 @@ int launch_lm(const LmPlan& p, const void* x, const void* w, const float* temps,
   const size_t lds = lds_x > lds_red ? lds_x : lds_red;
   static bool attr_set = false;
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lmhead_sample_kernel<MT, NT>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lmhead_sample_kernel<MT, NT, SB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       nvl_set_error("nvl_lmhead_sample: cannot reserve %zu B of LDS", lds);
       return NVL_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((lmhead_sample_kernel<MT, NT>), dim3((unsigned)p.groups), dim3(kNW * 64), lds, s,
+  hipLaunchKernelGGL((lmhead_sample_kernel<MT, NT, SB>), dim3((unsigned)p.groups), dim3(kNW * 64), lds, s,
                      (const bf16_t*)x, (const bf16_t*)w, temps, partial, (bf16_t*)logits, (int)batch, (int)vocab, k,
                      col_offset, seed, offset, offset_dev);
   return NVL_OK;
@@ -305,7 +309,7 @@ extern "C" int nvl_lmhead_sample(const void* x, const void* weight, const float*
               "nvl_lmhead_sample: bad col_offset=%lld", (long long)col_offset);
   LmPlan p;
   if (!lm_plan(batch, vocab_local, k, &p)) {
-    nvl_set_error("nvl_lmhead_sample: shape batch=%lld vocab=%lld k=%d not covered (batch <= 256, k %% 128 == 0)",
+    nvl_set_error("nvl_lmhead_sample: shape batch=%lld vocab=%lld k=%d not covered (batch <= 192, k / 128 a multiple of 8, 5 or 3)",
                   (long long)batch, (long long)vocab_local, k);
     return NVL_EUNSUPPORTED;
   }
@@ -314,13 +318,16 @@ extern "C" int nvl_lmhead_sample(const void* x, const void* weight, const float*
   hipStream_t s = (hipStream_t)stream;
   uint32_t* partial = (uint32_t*)workspace;
   int rc = NVL_EINVAL;
-#define NVL_LM_CASE(MT_, NT_)                                                                                   \
-  if (p.mt == MT_ && p.nt == NT_)                                                                               \
-    rc = launch_lm<MT_, NT_>(p, x, weight, temperatures, partial, logits_out, batch, vocab_local, k, col_offset, \
-                             seed, offset, offset_dev, s);
+#define NVL_LM_SB(MT_, NT_, SB_)                                                                                  \
+  if (p.sb == SB_)                                                                                                \
+    rc = launch_lm<MT_, NT_, SB_>(p, x, weight, temperatures, partial, logits_out, batch, vocab_local, k,         \
+                                  col_offset, seed, offset, offset_dev, s);
+#define NVL_LM_CASE(MT_, NT_)                                                                                     \
+  if (p.mt == MT_ && p.nt == NT_) { NVL_LM_SB(MT_, NT_, 8) NVL_LM_SB(MT_, NT_, 5) NVL_LM_SB(MT_, NT_, 3) }
   NVL_LM_CASE(1, 2) NVL_LM_CASE(2, 2) NVL_LM_CASE(3, 2) NVL_LM_CASE(5, 2) NVL_LM_CASE(7, 2) NVL_LM_CASE(9, 2)
-  NVL_LM_CASE(12, 1) NVL_LM_CASE(16, 1)
+  NVL_LM_CASE(12, 1)
 #undef NVL_LM_CASE
+#undef NVL_LM_SB
   if (rc != NVL_OK) {
     if (rc == NVL_EINVAL) nvl_set_error("nvl_lmhead_sample: internal plan error (mt=%d nt=%d)", p.mt, p.nt);
     return rc;

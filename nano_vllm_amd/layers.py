@@ -193,7 +193,7 @@ class Sampler(nn.Module):
     def forward_lm_head(self, hidden: torch.Tensor, weight: torch.Tensor, temperatures: torch.Tensor, out: torch.Tensor,
                         col_offset: int = 0, offset_dev: torch.Tensor | None = None) -> torch.Tensor | None:
         """lm_head GEMM + sampling in one pass (nvl_lmhead_sample): `hidden` [B, K] are the rows to sample from,
-        `weight` this rank's [V/tp, K] lm_head shard. Returns None when the shape is not covered (B > 256): the
+        `weight` this rank's [V/tp, K] lm_head shard. Returns None when the shape is not covered (B > 192): the
         caller then runs the GEMM and `forward` / `forward_shard`. TP > 1: the shard winners are exchanged and
         merged as in `forward_shard`."""
         b, k = hidden.shape
@@ -204,7 +204,7 @@ class Sampler(nn.Module):
         if need == 0:
             return None
         # sized ONCE for the largest covered batch of either tiling: captured graphs keep pointing at it
-        need = max(ops.lmhead_sample_workspace_bytes(144, v, k), ops.lmhead_sample_workspace_bytes(256, v, k))
+        need = max(ops.lmhead_sample_workspace_bytes(144, v, k), ops.lmhead_sample_workspace_bytes(192, v, k))
         if self._lm_ws is None or self._lm_ws.numel() < need or self._lm_ws.device != hidden.device:
             self._lm_ws = torch.empty(need, dtype=torch.uint8, device=hidden.device)
         offset = 0 if offset_dev is not None else self.calls

@@ -33,11 +33,11 @@ def graph_time(fn):
 res = {"cases": []}
 for name, v, k, copies in (("qwen3-0.6b", 151936, 1024, 4), ("qwen3-8b", 151936, 4096, 2), ("qwen3-32b/tp8", 18992, 5120, 8)):
     ws_list = [(torch.randn(v, k, device="cuda") * 0.05).to(BF16) for _ in range(copies)]
-    for b in (16, 64, 131, 144, 200, 256):
+    for b in (16, 64, 131, 144, 192):
         x = (torch.randn(b, k, device="cuda") * 0.5).to(BF16)
         temps = torch.full((b,), 0.6, device="cuda")
         out = torch.empty(b, dtype=torch.int64, device="cuda")
-        wsf = torch.empty(max(ops.lmhead_sample_workspace_bytes(144, v, k), ops.lmhead_sample_workspace_bytes(256, v, k)),
+        wsf = torch.empty(max(ops.lmhead_sample_workspace_bytes(144, v, k), ops.lmhead_sample_workspace_bytes(192, v, k)),
                           dtype=torch.uint8, device="cuda")
         wss = torch.empty(ops.sample_workspace_bytes(512), dtype=torch.uint8, device="cuda")
 
