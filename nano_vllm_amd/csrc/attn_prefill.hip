@@ -355,10 +355,14 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   const size_t lds = (size_t)2 * kTileBytes + 4 * sizeof(int) + (size_t)(num_seqs + 1) * sizeof(int);
   const float sl2 = softmax_scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
-  static int xcd_map = -1;                // NVL_PREFILL_XCD=0: plain (head, tile) grid, for A/B measurements
+  // NVL_PREFILL_XCD=1: XCD-aware workgroup numbering (see the kernel). Off by default — measured A/B on MI355X
+  // (profiles/r02_prefill_xcd{0,1}.json): 4 x 4096 +1.5 %, 8 x 2048 / G = 8 +1.5 %, 16 x 1024 +0.7 %, bench-like
+  // 29 x 561 -3 %, 1 x 16384 (16 / 8 heads) -12 %: co-locating a group's heads helps less than it hurts the
+  // longest-first balance across XCDs.
+  static int xcd_map = -1;
   if (xcd_map < 0) {
     const char* e = getenv("NVL_PREFILL_XCD");
-    xcd_map = (e && e[0] == '0') ? 0 : 1;
+    xcd_map = (e && e[0] == '1') ? 1 : 0;
   }
   dim3 grid((unsigned)num_q_heads, (unsigned)tiles);
   if (xcd_map) {

@@ -102,8 +102,12 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, de
 
 # NVL_FUSED_DECODE=0 keeps the separate q/k-norm+RoPE+KV-store launch on decode steps (A/B measurements)
 _FUSED_DECODE = os.environ.get("NVL_FUSED_DECODE", "1") != "0"
-# NVL_FUSED_LMHEAD=0 keeps lm_head GEMM (hipBLASLt) + nvl_sample as two steps with the logits in HBM
-_FUSED_LMHEAD = os.environ.get("NVL_FUSED_LMHEAD", "1") != "0"
+# NVL_FUSED_LMHEAD=1 samples inside the lm_head GEMM's epilogue (nvl_lmhead_sample: logits never in HBM). Off by
+# default: measured on MI355X (profiles/r02_lmhead_bench.json) the hand-written wide-tile kernel is bit-compatible
+# with GEMM + nvl_sample but slower than hipBLASLt + nvl_sample at decode batch sizes (Qwen3-0.6B head, 131 rows:
+# 148 vs 127 us; 16 rows: 78 vs 78 us) — its time grows with the row count (LDS-fragment latency per row tile), not
+# with the bytes streamed.
+_FUSED_LMHEAD = os.environ.get("NVL_FUSED_LMHEAD", "0") == "1"
 
 
 class Attention(nn.Module):

@@ -189,14 +189,18 @@ def _oracle_weights_06b(device):
     return cfg, {n: synth_tensor(n, s, 0, device=device).cpu() for n, s in parameter_shapes(cfg).items()}
 
 
-def test_qwen3_06b_shape_greedy_parity_vs_oracle(ckpt_06b):
-    """Full-size layers (fused decode attention G=2, skinny decode GEMMs at K=1024/2048/3072, sampler
+@pytest.mark.parametrize("fused_lm_head", [False, True])
+def test_qwen3_06b_shape_greedy_parity_vs_oracle(ckpt_06b, fused_lm_head, monkeypatch):
+    """(fused_lm_head: the opt-in nvl_lmhead_sample path — sampling inside the lm_head GEMM's epilogue.)
+    Full-size layers (fused decode attention G=2, skinny decode GEMMs at K=1024/2048/3072, sampler
     over 151,936 logits): every token we pick must be the CPU oracle's argmax (or within TOL) for the
     same history, with identical scheduling."""
     from oracle.engine import OracleEngine
     from oracle.model import OracleQwen3
+    import nano_vllm_amd.layers as layers_mod
+    monkeypatch.setattr(layers_mod, "_FUSED_LMHEAD", fused_lm_head)
     prompts = _prompts(3, 20, 300, 10000, seed=21)
-    max_tokens = [24, 22, 26]
+    max_tokens = [24, 22, 26] if not fused_lm_head else [8, 6, 7]
     outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, enforce_eager=False, max_model_len=1024,
                                 num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True)
     cfg, w = _oracle_weights_06b("cuda")
