@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--eager", action="store_true", help="enforce_eager=True (no hipGraph)")
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.9)
     ap.add_argument("--num-kvcache-blocks", type=int, default=-1)
+    ap.add_argument("--kv-cache-dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: opt-in OCP e4m3 KV cache (outside the reference's numerics; never the headline)")
     return ap.parse_args()
 
 
@@ -82,7 +84,8 @@ def workload(num_seqs: int, kind: str = "bench"):
 
 def engine_kwargs(args, tp: int) -> dict:
     kw = dict(enforce_eager=args.eager, max_model_len=4096, dummy_weights=True, tensor_parallel_size=tp,
-              gpu_memory_utilization=args.gpu_memory_utilization, num_kvcache_blocks=args.num_kvcache_blocks)
+              gpu_memory_utilization=args.gpu_memory_utilization, num_kvcache_blocks=args.num_kvcache_blocks,
+              kv_cache_dtype=args.kv_cache_dtype)
     if args.workload == "long":
         kw.update(max_model_len=32768, max_num_batched_tokens=16384)
     return kw
@@ -202,7 +205,7 @@ def base_result(args, tp, world_engines, n_gpus, elapsed, total_out, llm, parall
         "higher_is_better": True,
         "scaling": "weak" if tp == 1 else "strong",
         "vs_baseline": None,
-        "dtype": "bf16",
+        "dtype": "bf16" if args.kv_cache_dtype == "bf16" else "bf16 (KV cache fp8 e4m3: opt-in, outside parity)",
         "data": f"synthetic (seeded random weights, {args.model} shapes; token ids randint(0,10000) as reference bench.py)",
         "config": {"workload": workload_note(args), "parallelism": parallelism,
                    "hipgraph": not llm.model_runner.enforce_eager, "kv_blocks": llm.config.num_kvcache_blocks,
@@ -330,7 +333,7 @@ def run_replica(args, torch, dist, rank, world, tp, backend):
 
     if rank == 0 and not args.no_roofline and rec["samples"] and tp == 1:
         result["config"]["host_seconds_in_last_step"] = {k: round(v, 4) for k, v in host.items()}
-        result["roofline"] = roofline_replay(torch, runner, rec, args.model)
+        result["roofline"] = roofline_replay(torch, runner, rec, args.model if args.kv_cache_dtype == "bf16" else "no-pmc-pass")
         result["roofline"]["decode_step"] = decode_step_roofline(runner, rec, result, host["prefill_steps_s"])
         if rec.get("prefill"):
             result["roofline_prefill"] = prefill_replay(torch, runner, rec["prefill"])
@@ -349,7 +352,7 @@ def decode_step_roofline(runner, rec, result, prefill_s: float) -> dict:
     the last pass minus its prefill steps (host-timed: a prefill starts on a drained queue and ends in a sync)."""
     geo = runner.geo
     L, hkv = geo["layers"], geo["kv_heads"]
-    kv_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * 2 * L
+    kv_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * runner.kv_cache.element_size() * L
     # streamed once per step: every layer + the lm_head matrix (the tied embedding table when tie_word_embeddings);
     # the embedding GATHER touches only one row per sequence
     params = sum(p.numel() for n, p in runner.model.named_parameters()
@@ -371,10 +374,11 @@ def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
     hq, hkv, L = geo["heads"], geo["kv_heads"], geo["layers"]
     r = replay(torch, runner.kv_cache, rec["samples"], hq, hkv, runner.config.max_model_len, runner.decode_ws, fused=True)
     achieved = r["achieved_GBps"]
-    step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * 2 * L
+    step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * runner.kv_cache.element_size() * L
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"], model),
-            "kernel": (f"decode_stream_kernel<{hq // hkv}, fused>" if hq // hkv != 8 else "decode_mfma8_kernel<fused>")
+            "kernel": ((f"decode_stream_kernel<{hq // hkv}, fused>" if runner.kv_cache.element_size() == 2 else
+                        f"decode_stream_fp8_kernel<{hq // hkv}, fused>") if hq // hkv != 8 else "decode_mfma8_kernel<fused>")
                       + " + decode_stream_combine_kernel (nvl_paged_attn_decode_fused: the launch the decode step makes)",
             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],
             "launches_timed": r["launches_timed"], "decode_steps_in_pass": rec["steps"],

@@ -31,6 +31,11 @@
  * i.e. head-major inside a block, so one (block, kv-head) tile is one
  * contiguous block_size*256-byte run. slot = block*block_size + offset, as in
  * the reference (engine/model_runner.py:151-161,181).
+ *
+ * `kv_dtype` (entry points that touch the cache): NVL_KV_BF16 = the reference's cache
+ * precision (every parity run); NVL_KV_FP8 = opt-in OCP fp8 e4m3 cache (128 bytes per row,
+ * K/V rounded to nearest on store, exact on load): halves the bytes the decode step is bound
+ * by; an extension outside the reference's numerics. Group sizes 1, 2, 4.
  */
 #ifndef NVL_H_
 #define NVL_H_
@@ -46,6 +51,9 @@ extern "C" {
 #define NVL_EINVAL (-1)   /* bad argument (message in nvl_last_error) */
 #define NVL_ELAUNCH (-2)  /* HIP launch error */
 #define NVL_EUNSUPPORTED (-3)
+
+#define NVL_KV_BF16 0
+#define NVL_KV_FP8 1
 
 /* ABI version: bumped on any signature change. */
 int nvl_abi_version(void);
@@ -132,7 +140,7 @@ int nvl_store_kvcache(const void* k, int64_t k_tok_stride,
                       void* k_cache, void* v_cache,
                       const int32_t* slot_mapping,
                       int64_t n_tok, int num_kv_heads, int block_size,
-                      int64_t num_blocks, void* stream);
+                      int64_t num_blocks, int kv_dtype, void* stream);
 
 /* ---- Fused q/k-RMSNorm -> RoPE -> KV-cache store ("KF") -------------------
  * One launch for the four reference launches of models/qwen3.py:83-85 +
@@ -155,7 +163,7 @@ int nvl_qknorm_rope_kvstore(const void* qkv, int64_t qkv_tok_stride,
                             void* q_out, void* k_out,
                             void* k_cache, void* v_cache,
                             int64_t n_tok, int num_q_heads, int num_kv_heads,
-                            int block_size, int64_t num_blocks, void* stream);
+                            int block_size, int64_t num_blocks, int kv_dtype, void* stream);
 
 /* ---- Paged decode attention ------------------------------------------------
  * Replaces flash_attn_with_kvcache as called at layers/attention.py:72-74:
@@ -179,7 +187,7 @@ int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
                           int block_size, int64_t num_blocks, int64_t max_context,
                           float softmax_scale,
                           void* workspace, size_t workspace_bytes,
-                          void* stream);
+                          int kv_dtype, void* stream);
 
 /* Decode-step fusion of the three reference launches that precede the attention
  * call on a decode step — q/k RMSNorm (models/qwen3.py:82-84), rotary embedding
@@ -203,7 +211,7 @@ int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stride,
                                 int block_size, int64_t num_blocks, int64_t max_context,
                                 float softmax_scale,
                                 void* workspace, size_t workspace_bytes,
-                                void* stream);
+                                int kv_dtype, void* stream);
 
 /* ---- Varlen causal prefill attention (MFMA) ----------------------------------
  * Replaces flash_attn_varlen_func as called at layers/attention.py:67-70:
@@ -225,7 +233,7 @@ int nvl_attn_prefill_varlen(const void* q, const void* k, const void* v,
                             int64_t total_q, int num_seqs, int max_seqlen_q,
                             int num_q_heads, int num_kv_heads,
                             int block_size, int64_t num_blocks,
-                            float softmax_scale, void* stream);
+                            float softmax_scale, int kv_dtype, void* stream);
 
 /* ---- Token sampler ---------------------------------------------------------
  * Replaces Sampler.forward (layers/sampler.py:7-12):

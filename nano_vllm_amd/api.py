@@ -8,6 +8,8 @@ Extensions (all optional, behaviour-neutral when unset):
   * Config.seed seeds the counter-based sampler RNG.
   * Config.dummy_weights = True initialises random weights on device instead of reading
     *.safetensors (no 8B/32B checkpoints exist offline).
+  * Config.kv_cache_dtype = "fp8" stores K/V as OCP fp8 e4m3: the decode step is bound by
+    K/V bytes, this halves them. It changes numerics, so every parity run keeps the default "bf16".
 """
 from __future__ import annotations
 
@@ -42,6 +44,7 @@ class Config:
     # --- extensions -------------------------------------------------------------------------
     seed: int = 0
     dummy_weights: bool = False
+    kv_cache_dtype: str = "bf16"         # "fp8": OCP e4m3 KV cache (halves decode bytes; outside the reference's numerics)
 
     def __post_init__(self):
         assert os.path.isdir(self.model), f"model directory not found: {self.model}"
@@ -52,6 +55,7 @@ class Config:
             self.hf_config = AutoConfig.from_pretrained(self.model)
         self.max_model_len = min(self.max_model_len, self.hf_config.max_position_embeddings)
         assert self.max_num_batched_tokens >= 1 and self.max_num_seqs >= 1
+        assert self.kv_cache_dtype in ("bf16", "fp8"), "kv_cache_dtype must be 'bf16' or 'fp8'"
 
 
 def model_geometry(hf_config, tp: int = 1) -> dict:

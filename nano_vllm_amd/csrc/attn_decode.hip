@@ -301,6 +301,242 @@ __global__ __launch_bounds__(256, G == 4 ? 2 : 1) void decode_stream_kernel(   /
 }
 
 // ---------------------------------------------------------------------------------------------------
+// FP8 (OCP e4m3) KV-cache variant of decode_stream_kernel (opt-in, SURVEY.md §8f-4: decode is 92 % K/V bytes on the
+// headline workload, so halving the bytes per token is the only lever that moves the roofline IDEAL; it changes
+// numerics, so it stays outside the parity runs). Same stream-K bookkeeping, split-partial format and combine
+// kernel. What differs: a cache row is 128 BYTES, so one 16-byte load holds 16 elements and 8 lanes (half a DPP
+// row) cover a token: lane (r8 = lane >> 3, s8 = lane & 7) owns dims 16 s8 .. 16 s8 + 15 of rows 8 i + r8, and one
+// wave instruction still fetches 1 KiB contiguous (8 token rows). fp8 -> fp32 is one v_cvt_pk_f32_fp8 per two
+// elements (exact), the dot products are fp32 FMAs against the pre-unpacked q, reduced over the 8 lanes with three
+// DPP adds. FUSED: q/k are normed + rotated in the bf16 kernel's 16-lane layout and re-distributed once per
+// segment; the new token's k / v are QUANTISED before they enter this step's softmax, so a step sees exactly the
+// values every later step will read back from the cache.
+constexpr int kLoads8 = kTile / 8;       // 16-byte loads per lane per tile (K or V), 8 token rows each
+
+template <int G, bool FUSED>
+__global__ __launch_bounds__(256, G == 4 ? 2 : 1) void decode_stream_fp8_kernel(
+    const bf16_t* __restrict__ q, unsigned char* kc, unsigned char* vc, const int32_t* __restrict__ block_tables,
+    int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
+    int* __restrict__ meta, int batch, int hkv, int block_size, int slots, float scale_log2e, FusedArgs fa) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* wsum = reinterpret_cast<int*>(smem_raw);
+  int* pre = wsum + kWaves;
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane & 15, rq = lane >> 4;      // prologue view (16 lanes x 8 dims = one head row)
+  const int s8 = lane & 7, r8 = lane >> 3;        // tile view (8 lanes x 16 dims = one cache row)
+  const int hq = hkv * G;
+  // source lanes of the 16-lane layout holding this lane's two 8-element chunks (same 16-lane row group)
+  const int src_lo = (lane & 48) | (s8 * 2), src_hi = src_lo | 1;
+
+  chunk_prefix(ctx, batch, kTile, pre, wsum);
+  __syncthreads();
+  const int64_t total = (int64_t)pre[batch] * hkv;
+  const int64_t nwaves = (int64_t)gridDim.x * kWaves;
+  int64_t per = (total + nwaves - 1) / nwaves;
+  if (per < kMinTilesPerWave) per = kMinTilesPerWave;
+  const int64_t wid = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t g1 = min(total, (wid + 1) * per);
+
+  for (int64_t g = wid * per; g < g1;) {
+    int lo = 0, hi = batch;
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if ((int64_t)pre[mid] * hkv <= g) lo = mid; else hi = mid;
+    }
+    const int b = __builtin_amdgcn_readfirstlane(lo);
+    const int nb = __builtin_amdgcn_readfirstlane(pre[b + 1] - pre[b]);
+    const int64_t base_b = (int64_t)__builtin_amdgcn_readfirstlane(pre[b]) * hkv;
+    const int r = (int)(g - base_b);
+    const int h = r / nb;
+    const int t0 = r - h * nb;
+    const int run = (int)min((int64_t)(nb - t0), g1 - g);
+    const int len = ctx[b];
+    const bool owns_last = FUSED && (t0 + run == nb);
+
+    // ---- segment prologue in the 16-lane layout -------------------------------------------------------------
+    u32x4_t qf[G];
+    u32x4_t knew8 = {0u, 0u, 0u, 0u}, vnew8 = {0u, 0u, 0u, 0u};       // new token's row, 8-lane layout, fp8
+    if constexpr (FUSED) {
+      int64_t pos = len - 1;
+      pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
+      const bf16_t* row = q + (int64_t)b * fa.qkv_tok_stride;
+      const RopeRegs rr = load_rope_regs(fa.cos_sin + pos * 128, sub);
+      u32x4_t wq = {0u, 0u, 0u, 0u}, wk = {0u, 0u, 0u, 0u};
+      if (fa.q_norm_w != nullptr) {
+        wq = *reinterpret_cast<const u32x4_t*>(fa.q_norm_w + sub * 8);
+        wk = *reinterpret_cast<const u32x4_t*>(fa.k_norm_w + sub * 8);
+      }
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg)
+        qf[gg] = norm_rope_head_regs(*reinterpret_cast<const u32x4_t*>(row + (h * G + gg) * 128 + sub * 8),
+                                     fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
+      if (owns_last) {
+        u32x4_t knew = *reinterpret_cast<const u32x4_t*>(row + (hq + h) * 128 + sub * 8);
+        const u32x4_t vnew = *reinterpret_cast<const u32x4_t*>(row + (hq + hkv + h) * 128 + sub * 8);
+        knew = norm_rope_head_regs(knew, fa.k_norm_w != nullptr, wk, fa.eps, rr, sub);
+        const u32x2_t kq = bf16x8_to_fp8x8(knew), vq = bf16x8_to_fp8x8(vnew);
+        const int tl = len - 1;
+        if (rq == 0) {                                             // one 128-byte row each, for later steps
+          const int blk = block_tables[(int64_t)b * bt_stride + tl / block_size];
+          const int64_t dst = (((int64_t)blk * hkv + h) * block_size + (tl % block_size)) * 128 + sub * 8;
+          *reinterpret_cast<u32x2_t*>(kc + dst) = kq;
+          *reinterpret_cast<u32x2_t*>(vc + dst) = vq;
+        }
+        // quantised row -> 8-lane layout (16 bytes per lane)
+        knew8 = u32x4_t{(unsigned)__shfl((int)kq[0], src_lo, 64), (unsigned)__shfl((int)kq[1], src_lo, 64),
+                        (unsigned)__shfl((int)kq[0], src_hi, 64), (unsigned)__shfl((int)kq[1], src_hi, 64)};
+        vnew8 = u32x4_t{(unsigned)__shfl((int)vq[0], src_lo, 64), (unsigned)__shfl((int)vq[1], src_lo, 64),
+                        (unsigned)__shfl((int)vq[0], src_hi, 64), (unsigned)__shfl((int)vq[1], src_hi, 64)};
+      }
+    } else {
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg)
+        qf[gg] = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)b * hq + h * G + gg) * 128 + sub * 8);
+    }
+    // q -> 8-lane layout, unpacked to fp32: qv[gg][j] = q[16 s8 + j]
+    float qv[G][16];
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+      u32x4_t a, c;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a[i] = (unsigned)__shfl((int)qf[gg][i], src_lo, 64);
+        c[i] = (unsigned)__shfl((int)qf[gg][i], src_hi, 64);
+      }
+      unpack8(a, qv[gg]);
+      unpack8(c, qv[gg] + 8);
+    }
+
+    float m[G], l[G], o[G][16];
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+      m[gg] = kNegBig;
+      l[gg] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) o[gg][j] = 0.f;
+    }
+
+    u32x4_t kd[kLoads8], vd[kLoads8];
+    // one tile step on the rows held in kd / vd: row i * 8 + r8 of the tile is valid iff valid_row(i)
+    auto consume = [&](auto valid_row) {
+      float s[G][kLoads8];
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i) {
+        float kf[16];
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) unpack_fp8x4(kd[i][w4], kf + 4 * w4);
+        const bool valid = valid_row(i);
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg) {
+          float d = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) d = fmaf(kf[j], qv[gg][j], d);
+          d = half8_allreduce_sum(d);
+          s[gg][i] = valid ? d * scale_log2e : kNegBig;
+        }
+      }
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) {
+        float mx = s[gg][0];
+#pragma unroll
+        for (int i = 1; i < kLoads8; ++i) mx = fmaxf(mx, s[gg][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 8, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m[gg], mx);
+        const float alpha = exp2f(m[gg] - mn);
+        m[gg] = mn;
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i) {
+          const float p = exp2f(s[gg][i] - mn);
+          psum += p;
+          s[gg][i] = round_bf16(p);
+        }
+        l[gg] = l[gg] * alpha + psum;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) o[gg][j] *= alpha;
+      }
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i) {
+        float vf[16];
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) unpack_fp8x4(vd[i][w4], vf + 4 * w4);
+#pragma unroll
+        for (int gg = 0; gg < G; ++gg)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) o[gg][j] = fmaf(s[gg][i], vf[j], o[gg][j]);
+      }
+    };
+
+    if constexpr (FUSED) {
+      if (owns_last) {
+        // the new token is the first key of this wave's segment: a one-row tile (row 0 of row-group 0); its cache
+        // row is written above but never read back inside this launch — the tile loop masks row len - 1
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i) {
+          kd[i] = u32x4_t{0u, 0u, 0u, 0u};
+          vd[i] = u32x4_t{0u, 0u, 0u, 0u};
+        }
+        kd[0] = knew8;
+        vd[0] = vnew8;
+        consume([&](int i) { return i == 0 && r8 == 0; });
+      }
+    }
+    const int len_cached = FUSED ? len - 1 : len;
+
+    for (int ti = t0; ti < t0 + run; ++ti) {
+      const int t = ti * kTile;
+      const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
+      const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i)
+        kd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kc + base + i * 8 * 128));
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i)
+        vd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vc + base + i * 8 * 128));
+      __builtin_amdgcn_sched_barrier(0);  // all 8 loads in flight before the first use
+      consume([&](int i) { return (t + i * 8 + r8) < len_cached; });
+    }
+
+    // fold the wave's 8 row-groups and emit the partial of this (b, h) segment
+    const int64_t seg0 = base_b + (int64_t)h * nb;
+    const int first = (int)(seg0 / per);
+    const int k = (int)(wid - first);
+#pragma unroll
+    for (int gg = 0; gg < G; ++gg) {
+      l[gg] += __shfl_xor(l[gg], 8, 64);
+      l[gg] += __shfl_xor(l[gg], 16, 64);
+      l[gg] += __shfl_xor(l[gg], 32, 64);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        o[gg][j] += __shfl_xor(o[gg][j], 8, 64);
+        o[gg][j] += __shfl_xor(o[gg][j], 16, 64);
+        o[gg][j] += __shfl_xor(o[gg][j], 32, 64);
+      }
+    }
+    if (r8 == 0) {
+#pragma unroll
+      for (int gg = 0; gg < G; ++gg) {
+        const int64_t pidx = ((int64_t)b * hq + h * G + gg) * slots + k;
+        float* dst = part_o + pidx * 128 + s8 * 16;
+#pragma unroll
+        for (int j4 = 0; j4 < 4; ++j4)
+          *reinterpret_cast<f32x4_t*>(dst + 4 * j4) =
+              f32x4_t{o[gg][4 * j4], o[gg][4 * j4 + 1], o[gg][4 * j4 + 2], o[gg][4 * j4 + 3]};
+        if (s8 == 0) {
+          part_ml[pidx * 2] = m[gg];
+          part_ml[pidx * 2 + 1] = l[gg];
+        }
+      }
+      if (s8 == 0) meta[b * hkv + h] = (int)((seg0 + nb - 1) / per) - first + 1;
+    }
+    g += run;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // G = 8 (Qwen3-32B per-rank shapes at TP 4 / 8: one K/V row serves 8 query heads, 8 FLOP/B): the packed
 // v_dot2 path above is VALU-bound there (2.4 TB/s), so the scores and the P.V product go to the matrix
 // cores. Same stream-K bookkeeping, same split-partial format, same HBM->VGPR non-temporal tile loads;
@@ -627,6 +863,29 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
 }
 
 template <int G, bool FUSED>
+int launch_decode_stream_fp8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride,
+                             const int32_t* ctx, void* out, int64_t batch, int hkv, int block_size,
+                             int64_t max_context, float scale, void* workspace, hipStream_t s, const FusedArgs& fa) {
+  const int hq = hkv * G;
+  const int slots = stream_slots(max_context);
+  float* part_o = (float*)workspace;
+  float* part_ml = part_o + (size_t)batch * hq * slots * 128;
+  int* meta = (int*)(part_ml + (size_t)batch * hq * slots * 2);
+  const size_t lds = kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
+  int64_t grid = (int64_t)nvl_device_cu_count() * 2;
+  const int64_t max_tiles = batch * hkv * ((max_context + kTile - 1) / kTile);
+  const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
+  if (grid > max_wg) grid = max_wg;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL((decode_stream_fp8_kernel<G, FUSED>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
+                     (unsigned char*)kc, (unsigned char*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (int)batch, hkv,
+                     block_size, slots, scale * 1.4426950408889634f, fa);
+  hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
+                     meta, ctx, (bf16_t*)out, hq, hkv, slots);
+  return nvl_check_launch("nvl_paged_attn_decode");
+}
+
+template <int G, bool FUSED>
 int launch_decode_stream(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride,
                          const int32_t* ctx, void* out, int64_t batch, int hkv, int block_size, int64_t max_context,
                          float scale, void* workspace, hipStream_t s, const FusedArgs& fa) {
@@ -680,8 +939,9 @@ bool use_valu_g8() {
 int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* block_tables, int64_t bt_stride,
                   const int32_t* context_lens, void* out, int64_t batch, int num_q_heads, int num_kv_heads,
                   int block_size, int64_t num_blocks, int64_t max_context, float softmax_scale, void* workspace,
-                  size_t workspace_bytes, void* stream, const FusedArgs* fa, const char* who) {
+                  size_t workspace_bytes, void* stream, const FusedArgs* fa, const char* who, int kv_dtype) {
   NVL_REQUIRE(q && k_cache && v_cache && block_tables && context_lens && out && workspace, "%s: null pointer", who);
+  NVL_REQUIRE(kv_dtype == NVL_KV_BF16 || kv_dtype == NVL_KV_FP8, "%s: kv_dtype=%d (0 bf16, 1 fp8 e4m3)", who, kv_dtype);
   NVL_REQUIRE(batch >= 0 && batch <= 32768, "%s: batch=%lld out of range [0, 32768]", who, (long long)batch);
   NVL_REQUIRE(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "%s: Hq=%d not a multiple of Hkv=%d", who, num_q_heads, num_kv_heads);
   NVL_REQUIRE(block_size > 0 && block_size % kTile == 0, "%s: block_size=%d must be a multiple of %d", who, block_size, kTile);
@@ -695,6 +955,25 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
   NVL_REQUIRE(workspace_bytes >= need, "%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   const FusedArgs none = {};
+  if (kv_dtype == NVL_KV_FP8) {
+#define NVL_DECODE8_CASE(GG)                                                                                           \
+  case GG:                                                                                                             \
+    return fa ? launch_decode_stream_fp8<GG, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,   \
+                                                   batch, num_kv_heads, block_size, max_context, softmax_scale,       \
+                                                   workspace, s, *fa)                                                 \
+              : launch_decode_stream_fp8<GG, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
+                                                    batch, num_kv_heads, block_size, max_context, softmax_scale,      \
+                                                    workspace, s, none);
+    switch (G) {
+      NVL_DECODE8_CASE(1)
+      NVL_DECODE8_CASE(2)
+      NVL_DECODE8_CASE(4)
+      default:
+        nvl_set_error("%s: fp8 KV cache supports group sizes Hq/Hkv in {1, 2, 4} (got %d)", who, G);
+        return NVL_EUNSUPPORTED;
+    }
+#undef NVL_DECODE8_CASE
+  }
 #define NVL_DECODE_CASE(GG)                                                                                        \
   case GG:                                                                                                         \
     return fa ? launch_decode_stream<GG, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,   \
@@ -730,10 +1009,10 @@ extern "C" int nvl_paged_attn_decode(const void* q, const void* k_cache, const v
                                      const int32_t* block_tables, int64_t bt_stride, const int32_t* context_lens,
                                      void* out, int64_t batch, int num_q_heads, int num_kv_heads, int block_size,
                                      int64_t num_blocks, int64_t max_context, float softmax_scale, void* workspace,
-                                     size_t workspace_bytes, void* stream) {
+                                     size_t workspace_bytes, int kv_dtype, void* stream) {
   return decode_common(q, const_cast<void*>(k_cache), const_cast<void*>(v_cache), block_tables, bt_stride,
                        context_lens, out, batch, num_q_heads, num_kv_heads, block_size, num_blocks, max_context,
-                       softmax_scale, workspace, workspace_bytes, stream, nullptr, "nvl_paged_attn_decode");
+                       softmax_scale, workspace, workspace_bytes, stream, nullptr, "nvl_paged_attn_decode", kv_dtype);
 }
 
 extern "C" int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stride, const void* q_norm_w,
@@ -742,7 +1021,7 @@ extern "C" int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stri
                                            int64_t bt_stride, const int32_t* context_lens, void* out, int64_t batch,
                                            int num_q_heads, int num_kv_heads, int block_size, int64_t num_blocks,
                                            int64_t max_context, float softmax_scale, void* workspace,
-                                           size_t workspace_bytes, void* stream) {
+                                           size_t workspace_bytes, int kv_dtype, void* stream) {
   const char* who = "nvl_paged_attn_decode_fused";
   NVL_REQUIRE(cos_sin && max_pos > 0, "%s: rope table required", who);
   NVL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "%s: q/k norm weights must both be set or both NULL", who);
@@ -757,5 +1036,5 @@ extern "C" int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stri
   fa.eps = eps;
   return decode_common(qkv, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch, num_q_heads,
                        num_kv_heads, block_size, num_blocks, max_context, softmax_scale, workspace, workspace_bytes,
-                       stream, &fa, who);
+                       stream, &fa, who, kv_dtype);
 }

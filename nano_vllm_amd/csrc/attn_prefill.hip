@@ -42,7 +42,9 @@ struct SeqTile {
 
 constexpr int kTileBytes = kKBlk * (kKRowB + kVRowB);   // one K + V tile pair in LDS
 
-template <bool PAGED>
+// KV8 (PAGED only): the cache holds OCP fp8 e4m3 (128 bytes per (token, head) row); a staged tile is converted to
+// bf16 on its way into LDS (exact), everything downstream is unchanged.
+template <bool PAGED, bool KV8>
 __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_tok_stride,
     int64_t v_tok_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
@@ -177,8 +179,13 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     if constexpr (PAGED) {
       const int blk = block_tables[(int64_t)seq * bt_stride + kt / block_size];
       const int64_t base = (((int64_t)blk * hkv + kvh) * block_size + (kt % block_size)) * 128;
-      krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + base), 0, kKBlk * 256, 0x00020000);
-      vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + base), 0, kKBlk * 256, 0x00020000);
+      if constexpr (KV8) {
+        krs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)k + base), 0, kKBlk * 128, 0x00020000);
+        vrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)v + base), 0, kKBlk * 128, 0x00020000);
+      } else {
+        krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + base), 0, kKBlk * 256, 0x00020000);
+        vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + base), 0, kKBlk * 256, 0x00020000);
+      }
       ksoff = vsoff = 0;
     } else {
       krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)k0 * k_tok_stride + kvh * 128), 0,
@@ -188,21 +195,45 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
       ksoff = (int)(kt * kstride * 2);
       vsoff = (int)(kt * vstride * 2);
     }
+    if constexpr (KV8) {
+      // 64 keys x 128 B = 512 16-byte chunks: two per thread (chunk = tid + 256 n -> row chunk >> 3, 16 elements)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      kreg[n] = __builtin_amdgcn_raw_buffer_load_b128(krs, koff[n], ksoff, 0);
-      vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[n], vsoff, 0);
+      for (int n = 0; n < 2; ++n) {
+        kreg[n] = __builtin_amdgcn_raw_buffer_load_b128(krs, (tid + n * 256) * 16, ksoff, 0);
+        vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(vrs, (tid + n * 256) * 16, vsoff, 0);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        kreg[n] = __builtin_amdgcn_raw_buffer_load_b128(krs, koff[n], ksoff, 0);
+        vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[n], vsoff, 0);
+      }
     }
   };
   auto stage_write = [&](int buf) {     // registers -> LDS tile buffer `buf`
     unsigned char* kl = smem + buf * kTileBytes;
     unsigned char* vl = kl + kKBlk * kKRowB;
+    if constexpr (KV8) {
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int chunk = tid + n * 256;
-      const int row = chunk >> 4, c16 = chunk & 15;
-      *reinterpret_cast<u32x4_t*>(kl + row * kKRowB + ((c16 ^ (row & 15)) << 4)) = kreg[n];
-      *reinterpret_cast<u32x4_t*>(vl + row * kVRowB + (c16 << 4)) = vreg[n];
+      for (int n = 0; n < 2; ++n) {
+        const int chunk = tid + n * 256;
+        const int row = chunk >> 3, c16 = (chunk & 7) * 2;          // two bf16 16-byte chunks per fp8 chunk
+        u32x4_t a, b;
+        fp8x16_to_bf16(kreg[n], &a, &b);
+        *reinterpret_cast<u32x4_t*>(kl + row * kKRowB + ((c16 ^ (row & 15)) << 4)) = a;
+        *reinterpret_cast<u32x4_t*>(kl + row * kKRowB + (((c16 + 1) ^ (row & 15)) << 4)) = b;
+        fp8x16_to_bf16(vreg[n], &a, &b);
+        *reinterpret_cast<u32x4_t*>(vl + row * kVRowB + (c16 << 4)) = a;
+        *reinterpret_cast<u32x4_t*>(vl + row * kVRowB + ((c16 + 1) << 4)) = b;
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int chunk = tid + n * 256;
+        const int row = chunk >> 4, c16 = chunk & 15;
+        *reinterpret_cast<u32x4_t*>(kl + row * kKRowB + ((c16 ^ (row & 15)) << 4)) = kreg[n];
+        *reinterpret_cast<u32x4_t*>(vl + row * kVRowB + (c16 << 4)) = vreg[n];
+      }
     }
   };
   // keys this WAVE's 32 rows can see: tiles starting above wave_kmax carry no work for it
@@ -332,8 +363,10 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
                                        const int32_t* cu_seqlens_k, const int32_t* block_tables, int64_t bt_stride,
                                        void* out, int64_t total_q, int num_seqs, int max_seqlen_q, int num_q_heads,
                                        int num_kv_heads, int block_size, int64_t num_blocks, float softmax_scale,
-                                       void* stream) {
+                                       int kv_dtype, void* stream) {
   NVL_REQUIRE(q && k && v && cu_seqlens_q && cu_seqlens_k && out, "nvl_attn_prefill_varlen: null pointer");
+  NVL_REQUIRE(kv_dtype == NVL_KV_BF16 || (kv_dtype == NVL_KV_FP8 && block_tables != nullptr),
+              "nvl_attn_prefill_varlen: kv_dtype=%d (0 bf16; 1 fp8 e4m3 only with a paged cache)", kv_dtype);
   NVL_REQUIRE(total_q >= 0 && num_seqs >= 0 && num_seqs <= 32768, "nvl_attn_prefill_varlen: bad sizes (total_q=%lld, num_seqs=%d)", (long long)total_q, num_seqs);
   NVL_REQUIRE(num_kv_heads > 0 && num_q_heads > 0 && num_q_heads % num_kv_heads == 0 && num_q_heads <= 65535,
               "nvl_attn_prefill_varlen: Hq=%d must be a positive multiple of Hkv=%d", num_q_heads, num_kv_heads);
@@ -378,21 +411,27 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
     const size_t want = lds < 160 * 1024 ? lds + 16 * 1024 : lds;   // headroom: num_seqs moves it by a few KiB
     const size_t cap = want > 160 * 1024 ? 160 * 1024 : want;
     NVL_REQUIRE(lds <= 160 * 1024, "nvl_attn_prefill_varlen: %d sequences need %zu B of LDS (> 160 KiB)", num_seqs, lds);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<true>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<true, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<false>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<true, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<false, false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess) {
       nvl_set_error("nvl_attn_prefill_varlen: cannot reserve %zu B of LDS", cap);
       return NVL_ELAUNCH;
     }
     lds_cap = cap;
   }
-  if (paged) {
-    hipLaunchKernelGGL(prefill_attn_kernel<true>, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
+  if (paged && kv_dtype == NVL_KV_FP8) {
+    hipLaunchKernelGGL((prefill_attn_kernel<true, true>), grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables,
+                       bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map);
+  } else if (paged) {
+    hipLaunchKernelGGL((prefill_attn_kernel<true, false>), grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables,
                        bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map);
   } else {
-    hipLaunchKernelGGL(prefill_attn_kernel<false>, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
+    hipLaunchKernelGGL((prefill_attn_kernel<false, false>), grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables,
                        bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map);
   }

@@ -58,6 +58,35 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
   return w;
 }
 
+// ---- OCP fp8 (e4m3fn: what gfx950's conversion instructions implement) <-> fp32, 4 values per dword ----------
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ unsigned int pack_fp8x4(float a, float b, float c, float d) {
+  unsigned int w = 0;
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+  return w;
+}
+__device__ __forceinline__ void unpack_fp8x4(unsigned int w, float* f) {
+  const f32x2_t lo = __builtin_amdgcn_cvt_pk_f32_fp8(w, false);
+  const f32x2_t hi = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+  f[0] = lo[0]; f[1] = lo[1]; f[2] = hi[0]; f[3] = hi[1];
+}
+// 8 bf16 (one 16-byte chunk) -> 8 fp8 (8 bytes), round to nearest even
+__device__ __forceinline__ u32x2_t bf16x8_to_fp8x8(const u32x4_t& w) {
+  float f[8];
+  unpack8(w, f);
+  u32x2_t o = {pack_fp8x4(f[0], f[1], f[2], f[3]), pack_fp8x4(f[4], f[5], f[6], f[7])};
+  return o;
+}
+// 16 fp8 (16 bytes) -> two 16-byte chunks of bf16 (exact: every e4m3 value is a bf16 value)
+__device__ __forceinline__ void fp8x16_to_bf16(const u32x4_t& w, u32x4_t* lo, u32x4_t* hi) {
+  float f[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) unpack_fp8x4(w[i], f + 4 * i);
+  *lo = pack8(f);
+  *hi = pack8(f + 8);
+}
+
 // ---- cross-lane -----------------------------------------------------------------
 // Sum over the 16 lanes of a DPP row (lanes 16r..16r+15); every lane gets the total.
 __device__ __forceinline__ float row16_allreduce_sum(float v) {
@@ -65,6 +94,13 @@ __device__ __forceinline__ float row16_allreduce_sum(float v) {
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));  // row_ror:4
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));  // row_ror:2
   v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
+// Sum over the 8 lanes of a half DPP row (lanes 8r..8r+7); every lane gets the total.
+__device__ __forceinline__ float half8_allreduce_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xf, 0xf, false));  // row_half_mirror
   return v;
 }
 // Value held by the lane 8 positions away inside the same 16-lane row.

@@ -38,9 +38,21 @@ __global__ __launch_bounds__(256) void rope_kernel(const int64_t* __restrict__ p
   if (live) *reinterpret_cast<u32x4_t*>(out + tok * out_tok_stride + head * 128 + sub * 8) = pack8(o);
 }
 
+// One cache row of this lane's 8 elements: bf16 (16 bytes) or, KV8, OCP fp8 e4m3 (8 bytes; the cache then holds
+// 128 bytes per (token, head) row and every offset below is in BYTES = elements).
+template <bool KV8>
+__device__ __forceinline__ void put_row8(void* cache, int64_t elem_off, const u32x4_t& w) {
+  if constexpr (KV8) {
+    *reinterpret_cast<u32x2_t*>(static_cast<unsigned char*>(cache) + elem_off) = bf16x8_to_fp8x8(w);
+  } else {
+    *reinterpret_cast<u32x4_t*>(static_cast<bf16_t*>(cache) + elem_off) = w;
+  }
+}
+
+template <bool KV8>
 __global__ __launch_bounds__(256) void store_kv_kernel(const bf16_t* __restrict__ k, int64_t k_tok_stride,
                                                         const bf16_t* __restrict__ v, int64_t v_tok_stride,
-                                                        bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache,
+                                                        void* __restrict__ k_cache, void* __restrict__ v_cache,
                                                         const int32_t* __restrict__ slot_mapping, int64_t n_tok,
                                                         int num_kv_heads, int block_size) {
   const int64_t total = n_tok * num_kv_heads;
@@ -52,22 +64,21 @@ __global__ __launch_bounds__(256) void store_kv_kernel(const bf16_t* __restrict_
   const int64_t slot = slot_mapping[tok];
   if (slot < 0) return;  // layers/attention.py:23
   const int64_t dst = cache_row_offset(slot, head, num_kv_heads, block_size) + sub * 8;
-  *reinterpret_cast<u32x4_t*>(k_cache + dst) =
-      *reinterpret_cast<const u32x4_t*>(k + tok * k_tok_stride + head * 128 + sub * 8);
-  *reinterpret_cast<u32x4_t*>(v_cache + dst) =
-      *reinterpret_cast<const u32x4_t*>(v + tok * v_tok_stride + head * 128 + sub * 8);
+  put_row8<KV8>(k_cache, dst, *reinterpret_cast<const u32x4_t*>(k + tok * k_tok_stride + head * 128 + sub * 8));
+  put_row8<KV8>(v_cache, dst, *reinterpret_cast<const u32x4_t*>(v + tok * v_tok_stride + head * 128 + sub * 8));
 }
 
 // Fused: unit = (token, head) over Hq + 2*Hkv heads of the qkv GEMM output row.
 //   q head : norm -> rope -> q_out
 //   k head : norm -> rope -> k_out (optional) and k_cache[slot]
 //   v head : copy -> v_cache[slot]
+template <bool KV8>
 __global__ __launch_bounds__(256) void qknorm_rope_kvstore_kernel(
     const bf16_t* __restrict__ qkv, int64_t qkv_tok_stride, const int64_t* __restrict__ positions,
     const bf16_t* __restrict__ q_norm_w, const bf16_t* __restrict__ k_norm_w, float eps,
     const float* __restrict__ cos_sin, int64_t max_pos, const int32_t* __restrict__ slot_mapping,
-    bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_out, bf16_t* __restrict__ k_cache,
-    bf16_t* __restrict__ v_cache, int64_t n_tok, int hq, int hkv, int block_size) {
+    bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_out, void* __restrict__ k_cache,
+    void* __restrict__ v_cache, int64_t n_tok, int hq, int hkv, int block_size) {
   const int htot = hq + 2 * hkv;
   const int64_t total = n_tok * htot;
   const int64_t unit0 = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -82,7 +93,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvstore_kernel(
   if (head >= hq + hkv) {  // value head: straight copy into the cache
     if (live && slot >= 0) {
       const int kvh = head - hq - hkv;
-      *reinterpret_cast<u32x4_t*>(v_cache + cache_row_offset(slot, kvh, hkv, block_size) + sub * 8) = raw;
+      put_row8<KV8>(v_cache, cache_row_offset(slot, kvh, hkv, block_size) + sub * 8, raw);
     }
     return;  // whole 16-lane rows take this branch together; DPP below stays row-local
   }
@@ -101,8 +112,7 @@ __global__ __launch_bounds__(256) void qknorm_rope_kvstore_kernel(
   } else {
     const int kvh = head - hq;
     if (k_out != nullptr) *reinterpret_cast<u32x4_t*>(k_out + (tok * hkv + kvh) * 128 + sub * 8) = packed;
-    if (slot >= 0)
-      *reinterpret_cast<u32x4_t*>(k_cache + cache_row_offset(slot, kvh, hkv, block_size) + sub * 8) = packed;
+    if (slot >= 0) put_row8<KV8>(k_cache, cache_row_offset(slot, kvh, hkv, block_size) + sub * 8, packed);
   }
 }
 
@@ -125,8 +135,9 @@ extern "C" int nvl_rope_neox(const int64_t* positions, const float* cos_sin, int
 
 extern "C" int nvl_store_kvcache(const void* k, int64_t k_tok_stride, const void* v, int64_t v_tok_stride,
                                  void* k_cache, void* v_cache, const int32_t* slot_mapping, int64_t n_tok,
-                                 int num_kv_heads, int block_size, int64_t num_blocks, void* stream) {
+                                 int num_kv_heads, int block_size, int64_t num_blocks, int kv_dtype, void* stream) {
   NVL_REQUIRE(k && v && k_cache && v_cache && slot_mapping, "nvl_store_kvcache: null pointer");
+  NVL_REQUIRE(kv_dtype == NVL_KV_BF16 || kv_dtype == NVL_KV_FP8, "nvl_store_kvcache: kv_dtype=%d (0 bf16, 1 fp8 e4m3)", kv_dtype);
   NVL_REQUIRE(n_tok >= 0 && num_kv_heads > 0 && block_size > 0 && num_blocks > 0, "nvl_store_kvcache: bad sizes");
   NVL_REQUIRE(k_tok_stride % 8 == 0 && v_tok_stride % 8 == 0, "nvl_store_kvcache: strides must be multiples of 8");
   NVL_REQUIRE(((uintptr_t)k | (uintptr_t)v | (uintptr_t)k_cache | (uintptr_t)v_cache) % 16 == 0,
@@ -134,9 +145,14 @@ extern "C" int nvl_store_kvcache(const void* k, int64_t k_tok_stride, const void
   const int64_t total = n_tok * num_kv_heads;
   if (total == 0) return NVL_OK;
   NVL_REQUIRE((total + 15) / 16 < (1ll << 31), "nvl_store_kvcache: too many rows");
-  hipLaunchKernelGGL(store_kv_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)k, k_tok_stride, (const bf16_t*)v, v_tok_stride, (bf16_t*)k_cache,
-                     (bf16_t*)v_cache, slot_mapping, n_tok, num_kv_heads, block_size);
+  if (kv_dtype == NVL_KV_FP8)
+    hipLaunchKernelGGL(store_kv_kernel<true>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)k, k_tok_stride, (const bf16_t*)v, v_tok_stride, k_cache, v_cache, slot_mapping,
+                       n_tok, num_kv_heads, block_size);
+  else
+    hipLaunchKernelGGL(store_kv_kernel<false>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)k, k_tok_stride, (const bf16_t*)v, v_tok_stride, k_cache, v_cache, slot_mapping,
+                       n_tok, num_kv_heads, block_size);
   return nvl_check_launch("nvl_store_kvcache");
 }
 
@@ -144,8 +160,10 @@ extern "C" int nvl_qknorm_rope_kvstore(const void* qkv, int64_t qkv_tok_stride, 
                                        const void* q_norm_w, const void* k_norm_w, float eps, const float* cos_sin,
                                        int64_t max_pos, const int32_t* slot_mapping, void* q_out, void* k_out,
                                        void* k_cache, void* v_cache, int64_t n_tok, int num_q_heads,
-                                       int num_kv_heads, int block_size, int64_t num_blocks, void* stream) {
+                                       int num_kv_heads, int block_size, int64_t num_blocks, int kv_dtype,
+                                       void* stream) {
   NVL_REQUIRE(qkv && positions && cos_sin && q_out, "nvl_qknorm_rope_kvstore: null pointer");
+  NVL_REQUIRE(kv_dtype == NVL_KV_BF16 || kv_dtype == NVL_KV_FP8, "nvl_qknorm_rope_kvstore: kv_dtype=%d (0 bf16, 1 fp8 e4m3)", kv_dtype);
   NVL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "nvl_qknorm_rope_kvstore: q/k norm weights must both be set or both NULL");
   NVL_REQUIRE((k_cache == nullptr) == (v_cache == nullptr), "nvl_qknorm_rope_kvstore: k_cache/v_cache must both be set or both NULL");
   NVL_REQUIRE(k_cache == nullptr || slot_mapping != nullptr, "nvl_qknorm_rope_kvstore: slot_mapping required with a cache");
@@ -159,9 +177,15 @@ extern "C" int nvl_qknorm_rope_kvstore(const void* qkv, int64_t qkv_tok_stride, 
   const int64_t total = n_tok * (num_q_heads + 2 * num_kv_heads);
   if (total == 0) return NVL_OK;
   NVL_REQUIRE((total + 15) / 16 < (1ll << 31), "nvl_qknorm_rope_kvstore: too many rows");
-  hipLaunchKernelGGL(qknorm_rope_kvstore_kernel, dim3((unsigned)((total + 15) / 16)), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)qkv, qkv_tok_stride, positions, (const bf16_t*)q_norm_w,
-                     (const bf16_t*)k_norm_w, eps, cos_sin, max_pos, slot_mapping, (bf16_t*)q_out, (bf16_t*)k_out,
-                     (bf16_t*)k_cache, (bf16_t*)v_cache, n_tok, num_q_heads, num_kv_heads, block_size);
+  if (kv_dtype == NVL_KV_FP8)
+    hipLaunchKernelGGL(qknorm_rope_kvstore_kernel<true>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)qkv, qkv_tok_stride, positions, (const bf16_t*)q_norm_w,
+                       (const bf16_t*)k_norm_w, eps, cos_sin, max_pos, slot_mapping, (bf16_t*)q_out, (bf16_t*)k_out,
+                       k_cache, v_cache, n_tok, num_q_heads, num_kv_heads, block_size);
+  else
+    hipLaunchKernelGGL(qknorm_rope_kvstore_kernel<false>, dim3((unsigned)((total + 15) / 16)), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)qkv, qkv_tok_stride, positions, (const bf16_t*)q_norm_w,
+                       (const bf16_t*)k_norm_w, eps, cos_sin, max_pos, slot_mapping, (bf16_t*)q_out, (bf16_t*)k_out,
+                       k_cache, v_cache, n_tok, num_q_heads, num_kv_heads, block_size);
   return nvl_check_launch("nvl_qknorm_rope_kvstore");
 }

@@ -411,7 +411,10 @@ class ModelRunner:
         used = total - free
         stats = torch.cuda.memory_stats()
         peak, current = stats["allocated_bytes.all.peak"], stats["allocated_bytes.all.current"]
-        block_bytes = 2 * geo["layers"] * self.block_size * geo["kv_heads"] * geo["head_dim"] * 2
+        fp8 = cfg.kv_cache_dtype == "fp8"
+        if fp8:
+            assert geo["heads"] // geo["kv_heads"] in (1, 2, 4), "fp8 KV cache: group sizes 1, 2, 4 (see include/nvl.h)"
+        block_bytes = 2 * geo["layers"] * self.block_size * geo["kv_heads"] * geo["head_dim"] * (1 if fp8 else 2)
         if cfg.num_kvcache_blocks <= 0:
             assert not (self.world_size > 1 and os.environ.get("NVL_TP_SHARE_GPU") == "1"), \
                 "ranks sharing one GPU cannot size the KV cache from free memory: pass num_kvcache_blocks"
@@ -429,7 +432,10 @@ class ModelRunner:
         # tools/attn_replay.py --cache-blocks 9377 [--layer-major]). `kv_cache` keeps the [2, L, ...] indexing
         # as a transposed view.
         self._kv_storage = torch.zeros(geo["layers"], 2, cfg.num_kvcache_blocks, geo["kv_heads"], self.block_size,
-                                       geo["head_dim"], dtype=torch.bfloat16, device=self.device)
+                                       geo["head_dim"], dtype=torch.uint8 if fp8 else torch.bfloat16,
+                                       device=self.device)
+        if fp8:
+            self._kv_storage = self._kv_storage.view(torch.float8_e4m3fn)      # zero bytes are +0.0 in e4m3 too
         self.kv_cache = self._kv_storage.transpose(0, 1)
         layer = 0
         for module in self.model.modules():

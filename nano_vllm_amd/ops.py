@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnvl_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 # name -> (restype, argtypes); mirrors include/nvl.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -31,19 +31,20 @@ SIGNATURES = {
     "nvl_add_rmsnorm_splitk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "nvl_silu_mul": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "nvl_rope_neox": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
-    "nvl_store_kvcache": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_void_p]),
+    "nvl_store_kvcache": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64,
+                                  c_int, c_void_p]),
     "nvl_qknorm_rope_kvstore": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int64,
                                         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
-                                        c_int64, c_void_p]),
+                                        c_int64, c_int, c_void_p]),
     "nvl_paged_attn_decode_workspace_bytes": (c_size_t, [c_int64, c_int, c_int64]),
     "nvl_paged_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
-                                      c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
+                                      c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int, c_void_p]),
     "nvl_paged_attn_decode_fused": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p,
                                             c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
-                                            c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_void_p]),
+                                            c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int, c_void_p]),
     "nvl_attn_prefill_varlen": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                         c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
-                                        c_void_p]),
+                                        c_int, c_void_p]),
     "nvl_sample_workspace_bytes": (c_size_t, [c_int64]),
     "nvl_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_void_p,
                            c_void_p, c_size_t, c_void_p]),
@@ -107,6 +108,18 @@ def _check(rc: int) -> None:
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
+
+
+KV_BF16, KV_FP8 = 0, 1
+
+
+def kv_dtype_of(cache: torch.Tensor) -> int:
+    """NVL_KV_* code of a cache tensor: bf16 (the reference's precision) or OCP fp8 e4m3 (opt-in extension)."""
+    if cache.dtype == torch.bfloat16:
+        return KV_BF16
+    if cache.dtype == torch.float8_e4m3fn:
+        return KV_FP8
+    raise NvlError(f"unsupported KV-cache dtype {cache.dtype} (bfloat16 or float8_e4m3fn)")
 
 
 def _dev(t: torch.Tensor, name: str) -> None:
@@ -233,7 +246,7 @@ def store_kvcache(k: torch.Tensor, v: torch.Tensor, k_cache: torch.Tensor, v_cac
     assert slot_mapping.numel() == n
     _check(lib().nvl_store_kvcache(k.data_ptr(), k.stride(0), v.data_ptr(), v.stride(0), k_cache.data_ptr(),
                                    v_cache.data_ptr(), slot_mapping.data_ptr(), n, hkv, k_cache.shape[2],
-                                   k_cache.shape[0], _stream()))
+                                   k_cache.shape[0], kv_dtype_of(k_cache), _stream()))
 
 
 def qknorm_rope_kvstore(qkv: torch.Tensor, positions: torch.Tensor, q_norm_w, k_norm_w, eps: float,
@@ -251,7 +264,8 @@ def qknorm_rope_kvstore(qkv: torch.Tensor, positions: torch.Tensor, q_norm_w, k_
         q_out.data_ptr(), k_out.data_ptr() if k_out is not None else None,
         k_cache.data_ptr() if has_cache else None, v_cache.data_ptr() if has_cache else None,
         qkv.shape[0], num_q_heads, num_kv_heads,
-        k_cache.shape[2] if has_cache else 0, k_cache.shape[0] if has_cache else 0, _stream()))
+        k_cache.shape[2] if has_cache else 0, k_cache.shape[0] if has_cache else 0,
+        kv_dtype_of(k_cache) if has_cache else KV_BF16, _stream()))
 
 
 def paged_attn_decode_workspace_bytes(max_batch: int, num_q_heads: int, max_context: int) -> int:
@@ -271,7 +285,8 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
     _check(lib().nvl_paged_attn_decode(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(),
                                        block_tables.stride(0), context_lens.data_ptr(), out.data_ptr(), b, hq,
                                        k_cache.shape[1], k_cache.shape[2], k_cache.shape[0], max_context, scale,
-                                       workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+                                       workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                       kv_dtype_of(k_cache), _stream()))
     return out
 
 
@@ -293,7 +308,8 @@ def paged_attn_decode_fused(qkv: torch.Tensor, q_norm_w, k_norm_w, eps: float, c
         k_norm_w.data_ptr() if k_norm_w is not None else None, eps, cos_sin.data_ptr(), cos_sin.shape[0],
         k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(), block_tables.stride(0),
         context_lens.data_ptr(), out.data_ptr(), b, num_q_heads, k_cache.shape[1], k_cache.shape[2], k_cache.shape[0],
-        max_context, scale, workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
+        max_context, scale, workspace.data_ptr(), workspace.numel() * workspace.element_size(), kv_dtype_of(k_cache),
+        _stream()))
     return out
 
 
@@ -316,14 +332,14 @@ def attn_prefill_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_se
         _check(lib().nvl_attn_prefill_varlen(q.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0),
                                              cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), None, 0,
                                              out.data_ptr(), nq, num_seqs, max_seqlen_q, hq, hkv, 0, 0, scale,
-                                             _stream()))
+                                             KV_BF16, _stream()))
     else:
         assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
         _check(lib().nvl_attn_prefill_varlen(q.data_ptr(), k.data_ptr(), v.data_ptr(), 0, 0,
                                              cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(),
                                              block_tables.data_ptr(), block_tables.stride(0), out.data_ptr(), nq,
                                              num_seqs, max_seqlen_q, hq, k.shape[1], k.shape[2], k.shape[0], scale,
-                                             _stream()))
+                                             kv_dtype_of(k), _stream()))
     return out
 
 

@@ -429,3 +429,26 @@ def test_lookahead_and_microbatch_modes_reproduce_the_serial_engine(tiny_ckpt, m
 
     assert run(0.8) == run(0.8, NVL_LOOKAHEAD="0")
     assert run(0.0) == run(0.0, NVL_MICROBATCHES="2")
+
+
+def test_fp8_kv_cache_engine_runs_and_stays_close_to_the_bf16_engine(tiny_ckpt):
+    """kv_cache_dtype="fp8" end to end (prefill store, fused decode, chunked prefill reading the fp8 cache, hipGraph):
+    an extension outside the reference's numerics, so the bar is agreement with OUR bf16 engine on the first tokens
+    (one or two forward passes deep, before quantisation noise can flip a near-tie and the histories diverge)."""
+    from nano_vllm_amd import LLM, SamplingParams
+    prompts = _prompts(8, 5, 700, 512, seed=43)
+    sp = SamplingParams(temperature=0.0, max_tokens=16, ignore_eos=True)
+
+    def run(dt):
+        llm = LLM(tiny_ckpt, enforce_eager=False, max_model_len=2048, num_kvcache_blocks=32, max_num_seqs=8,
+                  max_num_batched_tokens=640, kv_cache_dtype=dt)
+        outs = [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
+        llm.exit()
+        return outs
+
+    a, b = run("bf16"), run("fp8")
+    assert all(len(t) == 16 for t in b)
+    first = sum(x[0] == y[0] for x, y in zip(a, b))
+    agree = sum(sum(p == q for p, q in zip(x, y)) for x, y in zip(a, b)) / (16 * len(a))
+    print(f"fp8 KV vs bf16 KV: first tokens equal {first}/{len(a)}, all positions equal {agree:.2f}")
+    assert first >= len(a) - 1

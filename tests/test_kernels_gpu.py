@@ -489,6 +489,132 @@ def test_prefill_paged_continuation_of_a_prompt_longer_than_the_token_budget(ops
 
 
 # ------------------------------------------------------------------------------------------
+# Opt-in fp8 (OCP e4m3) KV cache. Oracle = the same restatement evaluated on a cache whose values
+# went through torch's own float8_e4m3fn cast: the store must reproduce that cast BIT FOR BIT (round to nearest
+# even), the attention kernels must agree with the oracle on the dequantised cache to the bf16-path tolerance.
+def _fp8_roundtrip(t):
+    return t.to(torch.float8_e4m3fn).to(BF16)
+
+
+@pytest.mark.parametrize("n,h,hkv", [(1, 16, 8), (131, 16, 8), (40, 32, 8)])
+def test_fp8_kv_store_matches_torch_cast_bit_for_bit(ops, n, h, hkv):
+    gen = g(120 + n)
+    bs, nblk = 256, 4
+    qkv = (torch.randn(n, (h + 2 * hkv) * 128, generator=gen) * 3).to(BF16)
+    pos = torch.randint(0, 2000, (n,), generator=gen)
+    slots = torch.randperm(nblk * bs, generator=gen)[:n].to(torch.int32)
+    slots[0] = -1 if n > 1 else slots[0]
+    qw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16)
+    kw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16)
+    inv = 1.0 / (1e6 ** (torch.arange(0, 128, 2).float() / 128))
+    fr = torch.arange(2048).float()[:, None] * inv[None]
+    table = torch.cat([fr.cos(), fr.sin()], -1).contiguous()
+    caches = {}
+    for name, dt in (("bf16", BF16), ("fp8", torch.float8_e4m3fn)):
+        kc = torch.zeros(nblk, hkv, bs, 128, dtype=torch.uint8 if dt != BF16 else BF16, device="cuda")
+        vc = torch.zeros_like(kc)
+        if dt != BF16:
+            kc, vc = kc.view(dt), vc.view(dt)
+        q = torch.empty(n, h, 128, dtype=BF16, device="cuda")
+        ops.qknorm_rope_kvstore(dev(qkv), dev(pos), dev(qw), dev(kw), 1e-6, dev(table), dev(slots), q, None, kc, vc, h, hkv)
+        caches[name] = (kc, vc)
+    for i in (0, 1):
+        want = caches["bf16"][i].cpu().to(torch.float8_e4m3fn)
+        assert torch.equal(caches["fp8"][i].cpu().view(torch.uint8), want.view(torch.uint8))
+    # plain store entry point
+    k = (torch.randn(n, hkv, 128, generator=gen) * 2).to(BF16)
+    v = (torch.randn(n, hkv, 128, generator=gen) * 2).to(BF16)
+    kc = torch.zeros(nblk, hkv, bs, 128, dtype=torch.uint8, device="cuda").view(torch.float8_e4m3fn)
+    vc = torch.zeros_like(kc)
+    ops.store_kvcache(dev(k), dev(v), kc, vc, dev(slots))
+    ref_k = torch.zeros(nblk * bs, hkv, 128, dtype=BF16)
+    keep = slots >= 0
+    ref_k[slots[keep].long()] = k[keep]
+    got = kc.cpu().view(torch.uint8).view(nblk, hkv, bs, 128).permute(0, 2, 1, 3).reshape(nblk * bs, hkv, 128)
+    assert torch.equal(got, ref_k.to(torch.float8_e4m3fn).view(torch.uint8))
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8)])
+@pytest.mark.parametrize("lens", [[1], [255, 256, 257, 33], [1, 100, 1023, 1024, 1025, 2048, 17, 0, 640], [4096, 3, 0, 700]])
+def test_fp8_kv_decode_fused_vs_oracle_on_the_dequantised_cache(ops, hq, hkv, lens):
+    """nvl_paged_attn_decode_fused with an fp8 cache: (1) the new token's K/V rows land in the cache as the fp8 cast
+    of what the bf16 path stores; (2) the output equals the oracle's flash_attn_with_kvcache over the DEQUANTISED
+    cache (which includes the new token's quantised row: this step sees what later steps will read)."""
+    bs, max_ctx = 256, 4096
+    gen = g(130)
+    b = len(lens)
+    nb = [(n + bs - 1) // bs for n in lens]
+    total = sum(nb) + 3
+    kc16 = _fp8_roundtrip(torch.randn(total, hkv, bs, 128, generator=gen).to(BF16))
+    vc16 = _fp8_roundtrip(torch.randn(total, hkv, bs, 128, generator=gen).to(BF16))
+    perm = torch.randperm(total, generator=gen).tolist()
+    bt = torch.full((b, max_ctx // bs), -1, dtype=torch.int32)
+    c = 0
+    for s_, n in enumerate(nb):
+        for j in range(n):
+            bt[s_, j] = perm[c]
+            c += 1
+    qkv = torch.randn(b, (hq + 2 * hkv) * 128, generator=gen).to(BF16)
+    qw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16)
+    kw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16)
+    inv = 1.0 / (1e6 ** (torch.arange(0, 128, 2).float() / 128))
+    fr = torch.arange(max_ctx).float()[:, None] * inv[None]
+    table = torch.cat([fr.cos(), fr.sin()], -1).contiguous()
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    pos = (ctx.long() - 1).clamp(min=0)
+    slots = torch.tensor([int(bt[i, (n - 1) // bs]) * bs + (n - 1) % bs if n > 0 else -1 for i, n in enumerate(lens)],
+                         dtype=torch.int32)
+    scale = 128 ** -0.5
+    # reference: bf16 pipeline for q / new k, v; then quantise the cache rows
+    kc_ref, vc_ref = dev(kc16.clone()), dev(vc16.clone())
+    q1 = torch.empty(b, hq, 128, dtype=BF16, device="cuda")
+    ops.qknorm_rope_kvstore(dev(qkv), dev(pos), dev(qw), dev(kw), 1e-6, dev(table), dev(slots), q1, None, kc_ref, vc_ref, hq, hkv)
+    kc_deq, vc_deq = _fp8_roundtrip(kc_ref.cpu()), _fp8_roundtrip(vc_ref.cpu())
+    # ours: fp8 cache holding the same values
+    kc8 = dev(kc16.to(torch.float8_e4m3fn))
+    vc8 = dev(vc16.to(torch.float8_e4m3fn))
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    o = ops.paged_attn_decode_fused(dev(qkv), dev(qw), dev(kw), 1e-6, dev(table), kc8, vc8, dev(bt), dev(ctx), hq, scale,
+                                    max_ctx, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(kc8.cpu().view(torch.uint8), kc_deq.to(torch.float8_e4m3fn).view(torch.uint8))
+    assert torch.equal(vc8.cpu().view(torch.uint8), vc_deq.to(torch.float8_e4m3fn).view(torch.uint8))
+    live = [i for i, n in enumerate(lens) if n > 0]
+    o_ref = ref.flash_attn_with_kvcache(q1.cpu().unsqueeze(1), ref.from_head_major(kc_deq), ref.from_head_major(vc_deq),
+                                        ctx, bt, scale).squeeze(1)
+    d = (o.cpu().float()[live] - o_ref.float()[live]).abs().max()
+    assert float(d) <= 2e-2 * float(o_ref.float()[live].abs().max()) + 1e-3
+    for i, n in enumerate(lens):
+        if n == 0:
+            assert not o[i].any()
+    # unfused entry on the same cache
+    o2 = ops.paged_attn_decode(q1, kc8, vc8, dev(bt), dev(ctx), scale, max_ctx, torch.zeros_like(ws))
+    d2 = (o2.cpu().float()[live] - o_ref.float()[live]).abs().max()
+    assert float(d2) <= 2e-2 * float(o_ref.float()[live].abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8)])
+def test_fp8_kv_prefill_paged_prefix(ops, hq, hkv):
+    """Prefix-cache / chunk-continuation prefill reading an fp8 cache == the oracle on the dequantised cache."""
+    bs = 256
+    lq_lk = [(100, 356), (256, 256), (7, 1031), (300, 812)]
+    lqs = [a for a, _ in lq_lk]
+    lks = [b for _, b in lq_lk]
+    kc, vc, bt = _paged_setup(lks, hkv, bs, seed=140)
+    kc, vc = _fp8_roundtrip(kc), _fp8_roundtrip(vc)
+    gen = g(141)
+    q = torch.randn(sum(lqs), hq, 128, generator=gen).to(BF16)
+    cuq, cuk = _cu(lqs), _cu(lks)
+    scale = 128 ** -0.5
+    o_ref = ref.flash_attn_varlen_func(q, kc, vc, max(lqs), cuq, max(lks), cuk, scale, True, bt)
+    o = ops.attn_prefill_varlen(dev(q), dev(ref.to_head_major(kc).to(torch.float8_e4m3fn)),
+                                dev(ref.to_head_major(vc).to(torch.float8_e4m3fn)), dev(cuq), dev(cuk), max(lqs), scale,
+                                block_tables=dev(bt))
+    err = (o.cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+
+
+# ------------------------------------------------------------------------------------------
 def test_sampler_greedy_exact(ops):
     b, vocab = 37, 151936
     logits = torch.randn(b, vocab, generator=g(70)).to(BF16)

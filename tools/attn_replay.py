@@ -103,7 +103,7 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
             stop.record()
             torch.cuda.synchronize()
         total_ms += start.elapsed_time(stop)
-        total_bytes += int(ctx.sum()) * 2 * hkv * 128 * 2 * L
+        total_bytes += int(ctx.sum()) * 2 * hkv * 128 * kv_cache.element_size() * L
         launches += L
     return dict(achieved_GBps=total_bytes / (total_ms * 1e-3) / 1e9, algorithmic_bytes_per_launch=total_bytes / launches,
                 avg_launch_us=total_ms * 1e3 / launches, launches_timed=launches, reps=reps)
