@@ -42,6 +42,17 @@ prefillx)
   for x in 0 1; do NVL_PREFILL_XCD=$x timeout 600 python tools/prefill_bench.py > $OUT/prefill_xcd$x.json 2> $OUT/prefill_xcd$x.err; echo "prefill xcd=$x rc=$?"; cat $OUT/prefill_xcd$x.json; echo; done;;
 newtests)
   timeout 1200 python -m pytest tests -m gpu -q -rf -k "lmhead or prefill or logits or tiny_model_greedy or tp2 or sampler or 06b_shape_greedy" > $OUT/pytest_new.log 2>&1; echo "newtests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_new.log | tail -20;;
+fp8)
+  timeout 900 python -m pytest tests -m gpu -q -rf -k "fp8" > $OUT/pytest_fp8.log 2>&1; echo "fp8 tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|fp8 KV vs" $OUT/pytest_fp8.log | tail -12
+  timeout 600 python bench.py --kv-cache-dtype fp8 --no-cpu-baseline > $OUT/bench_fp8kv.json 2> $OUT/bench_fp8kv.err; echo "bench fp8 rc=$?"; tail -c 400 $OUT/bench_fp8kv.err; cut -c1-1500 $OUT/bench_fp8kv.json;;
+cfg3)
+  timeout 900 python bench.py --model qwen3-8b --workload prefix --no-cpu-baseline --warmup 0 > $OUT/bench_cfg3_8b_prefix.json 2> $OUT/bench_cfg3.err; echo "cfg3 rc=$?"; tail -c 300 $OUT/bench_cfg3.err; cut -c1-1200 $OUT/bench_cfg3_8b_prefix.json;;
+tpfunc)
+  timeout 600 python tools/tp_functional.py qwen3-32b 2 8 48 > $OUT/tp_functional_32b_tp2.json 2> $OUT/tp_functional.err; echo "tpfunc rc=$?"; tail -c 800 $OUT/tp_functional.err; cat $OUT/tp_functional_32b_tp2.json;;
+pmcprefill)
+  (cd /tmp && rocprofv3 -L > $OUT/rocprof_counters.txt 2>&1; grep -c . $OUT/rocprof_counters.txt; grep -o -E "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*|SQ_LDS_BANK_CONFLICT|SQ_LDS_IDX_ACTIVE|SQ_INSTS_VALU\b|SQ_WAVE_CYCLES|SQ_BUSY_CYCLES|SQ_BUSY_CU_CYCLES" $OUT/rocprof_counters.txt | sort -u | tr '\n' ' '; echo
+   timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_prefill -o pf -- python $REPO/tools/prefill_bench.py > $OUT/prefill_under_pmc.json 2> $OUT/prefill_pmc.err; echo "pmcprefill rc=$?"; tail -c 500 $OUT/prefill_pmc.err)
+  f=$(find /tmp/pmc_prefill -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_prefill_summary.py $f $OUT/prefill_pmc_summary.json && cat $OUT/prefill_pmc_summary.json;;
 replay)
   timeout 600 python tools/attn_replay.py --fused > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
 *) echo "unknown step $w";;
