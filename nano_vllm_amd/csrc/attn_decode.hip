@@ -486,10 +486,46 @@ __global__ __launch_bounds__(256, G == 4 ? 2 : 1) void decode_stream_fp8_kernel(
     }
     const int len_cached = FUSED ? len - 1 : len;
 
-    for (int ti = t0; ti < t0 + run; ++ti) {
+    // A 32-token fp8 tile is only 8 KiB per wave; the bf16 kernel keeps 16 KiB in flight. With G <= 2 there are
+    // registers for TWO tiles: load both (16 loads), then consume both.
+    constexpr bool kPair = G <= 2;
+    auto tile_base = [&](int ti) {
       const int t = ti * kTile;
       const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
-      const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;
+      return (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;
+    };
+    int ti = t0;
+    if constexpr (kPair) {
+      u32x4_t kd2[kLoads8], vd2[kLoads8];
+      for (; ti + 1 < t0 + run; ti += 2) {
+        const int64_t b0 = tile_base(ti), b1 = tile_base(ti + 1);
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i)
+          kd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kc + b0 + i * 8 * 128));
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i)
+          vd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vc + b0 + i * 8 * 128));
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i)
+          kd2[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kc + b1 + i * 8 * 128));
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i)
+          vd2[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vc + b1 + i * 8 * 128));
+        __builtin_amdgcn_sched_barrier(0);  // all 16 loads in flight before the first use
+        const int ta = ti * kTile;
+        consume([&](int i) { return (ta + i * 8 + r8) < len_cached; });
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i) {
+          kd[i] = kd2[i];
+          vd[i] = vd2[i];
+        }
+        const int tb = ta + kTile;
+        consume([&](int i) { return (tb + i * 8 + r8) < len_cached; });
+      }
+    }
+    for (; ti < t0 + run; ++ti) {
+      const int t = ti * kTile;
+      const int64_t base = tile_base(ti);
 #pragma unroll
       for (int i = 0; i < kLoads8; ++i)
         kd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kc + base + i * 8 * 128));
@@ -837,7 +873,8 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
   float* part_ml = part_o + (size_t)batch * hq * slots * 128;
   int* meta = (int*)(part_ml + (size_t)batch * hq * slots * 2);
   const size_t lds = (size_t)kWaves * kMWaveLds + kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
-  static bool attr_set = false;
+  static bool attr_done[NVL_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_kernel<FUSED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
@@ -847,8 +884,7 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
     attr_set = true;
   }
   NVL_REQUIRE(lds <= 160 * 1024, "nvl_paged_attn_decode: batch=%lld needs %zu B of LDS (> 160 KiB)", (long long)batch, lds);
-  static int cus = 0;
-  if (cus == 0) cus = nvl_device_cu_count();
+  const int cus = nvl_device_cu_count();
   int64_t grid = (int64_t)cus * (2 * lds <= 160 * 1024 ? 2 : 1);
   const int64_t max_tiles = batch * hkv * ((max_context + kTile - 1) / kTile);
   const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
@@ -895,9 +931,10 @@ int launch_decode_stream(const void* q, void* kc, void* vc, const int32_t* bt, i
   float* part_ml = part_o + (size_t)batch * hq * slots * 128;
   int* meta = (int*)(part_ml + (size_t)batch * hq * slots * 2);
   const size_t lds = kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
-  static int cus = 0, per_cu = 0;
-  if (cus == 0) {
-    cus = nvl_device_cu_count();
+  static int per_cu_dev[NVL_MAX_DEVICES] = {};
+  int& per_cu = per_cu_dev[nvl_device_slot()];
+  const int cus = nvl_device_cu_count();
+  if (per_cu == 0) {
     int n = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, decode_stream_kernel<G, FUSED>, 256, lds) != hipSuccess || n < 1) n = 2;
     // 2 workgroups (8 waves, 128 KiB of loads in flight) per CU saturate HBM; measured on the bench replay:

@@ -406,7 +406,8 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   } else {
     NVL_REQUIRE(tiles <= 65535, "nvl_attn_prefill_varlen: too many query tiles (%lld)", (long long)tiles);
   }
-  static size_t lds_cap = 0;            // dynamic LDS above 64 KiB must be opted into per kernel
+  static size_t lds_caps[NVL_MAX_DEVICES] = {};   // dynamic LDS above 64 KiB must be opted into per kernel (and device)
+  size_t& lds_cap = lds_caps[nvl_device_slot()];
   if (lds > lds_cap) {
     const size_t want = lds < 160 * 1024 ? lds + 16 * 1024 : lds;   // headroom: num_seqs moves it by a few KiB
     const size_t cap = want > 160 * 1024 ? 160 * 1024 : want;

@@ -21,6 +21,10 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 // ---- host-side error plumbing -------------------------------------------------
 void nvl_set_error(const char* fmt, ...);
 int nvl_check_launch(const char* what);
+// Launcher-side caches (CU count, per-kernel LDS opt-in) are kept PER DEVICE so the entry points are re-entrant
+// per device: index of the calling thread's current HIP device, clamped to the table size.
+#define NVL_MAX_DEVICES 16
+int nvl_device_slot(void);
 
 #define NVL_REQUIRE(cond, ...)            \
   do {                                    \

@@ -523,7 +523,8 @@ int launch(const void* x, const void* w, void* out, int64_t m, int n, int k, con
   const size_t lds_red = (size_t)(kNW / 2) * MT * NT * 64 * sizeof(f32x4_t);
   const size_t lds_ring = (size_t)kNW * 2 * XTile<KB>::kBytes;
   const size_t lds = lds_red > lds_ring ? lds_red : lds_ring;
-  static bool attr_set = false;
+  static bool attr_done[NVL_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_decode_kernel<MT, KB, NT, EPI>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -544,7 +545,8 @@ int launch_multi(const void* x, const void* w, void* out, int64_t m, int n, int 
   const size_t lds_red = (size_t)(kNW / 2) * MT * NT * 64 * sizeof(f32x4_t);
   const size_t lds_ring = (size_t)kNW * 2 * XTile<KB>::kBytes;
   const size_t lds = lds_red > lds_ring ? lds_red : lds_ring;
-  static bool attr_set = false;
+  static bool attr_done[NVL_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_decode_multi_kernel<MT, KB, NT, EPI, NSET>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

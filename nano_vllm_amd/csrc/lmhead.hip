@@ -274,7 +274,8 @@ int launch_lm(const LmPlan& p, const void* x, const void* w, const float* temps,
   const size_t lds_x = (size_t)2 * MT * 16 * 256;
   const size_t lds_red = (size_t)kNW * MT * 16 * sizeof(Best);
   const size_t lds = lds_x > lds_red ? lds_x : lds_red;
-  static bool attr_set = false;
+  static bool attr_done[NVL_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set && lds > 64 * 1024) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&lmhead_sample_kernel<MT, NT, SB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {

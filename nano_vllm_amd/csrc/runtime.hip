@@ -26,9 +26,19 @@ extern "C" int nvl_abi_version(void) { return 2; }   // 2: kv_dtype arguments, c
 
 extern "C" const char* nvl_last_error(void) { return g_err; }
 
+int nvl_device_slot(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) return 0;
+  return dev < NVL_MAX_DEVICES ? dev : NVL_MAX_DEVICES - 1;
+}
+
 extern "C" int nvl_device_cu_count(void) {
+  static int cache[NVL_MAX_DEVICES] = {};
   int dev = 0, n = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 256;
+  const int slot = dev >= 0 && dev < NVL_MAX_DEVICES ? dev : -1;
+  if (slot >= 0 && cache[slot] > 0) return cache[slot];
   if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+  if (slot >= 0) cache[slot] = n;
   return n;
 }

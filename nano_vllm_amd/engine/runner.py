@@ -316,6 +316,7 @@ class ModelRunner:
             op, args, body = ch.recv()
             if op == _Channel.OP_EXIT:
                 ch.ack(self.rank)
+                del args, body                 # views into the shared segment: it cannot be unmapped while they live
                 self.exit()
                 break
             if op == _Channel.OP_DECODE:
