@@ -108,17 +108,20 @@ class LLMEngine:
         self._unfilled = None
         if seqs is None:
             return []
+        before = {s.seq_id for s in seqs if s.is_finished and s.token_ids[-1] != self.scheduler.PLACEHOLDER}
         self.scheduler.fill_tokens(seqs, self.model_runner.call("decode_end"))
-        return [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished]
+        # (a sequence that had already finished by EOS in the step before was reported then)
+        return [(s.seq_id, s.completion_token_ids) for s in seqs if s.is_finished and s.seq_id not in before]
 
     def _step_lookahead(self, pending):
-        """One engine step for `generate()`. Same results and the same sequence of scheduler / block-manager
-        operations as `step()`; when a decode step's bookkeeping does not depend on the sampled tokens (all
-        sequences ignore_eos, TP = 1) the host runs ahead of the GPU ("overlap
-        schedule(N+1) with GPU(N)"): step N+1 is ENQUEUED before step N's ids have reached the host — its
-        input ids are taken from step N's output on the device (nvl_feed_tokens) — then step N is collected,
-        and postprocess (token values filled in afterwards), schedule and staging of step N+2 run while the
-        GPU works. The GPU queue never drains between decode steps. Finished sequences of a lookahead step
+        """One engine step for `generate()`. Same results as `step()`; on decode steps the host runs ahead of the
+        GPU ("overlap schedule(N+1) with GPU(N)"): step N+1 is ENQUEUED before step N's ids
+        have reached the host — its input ids are taken from step N's output on the device (nvl_feed_tokens) —
+        then step N is collected, and postprocess (token values filled in afterwards), schedule and staging of
+        step N+2 run while the GPU works. The GPU queue never drains between decode steps. With `ignore_eos` the
+        scheduler and block manager go through exactly the serial loop's operations; a sequence that samples EOS
+        is discovered one step late and finished retroactively (sched.Scheduler.fill_tokens): its outputs are the
+        serial loop's, only its last step's row was computed for nothing. Finished sequences of a lookahead step
         are reported by the next call.
         `pending`: None, or (seqs, is_prefill, staged) scheduled by the previous call.
         Returns (finished outputs, num_tokens, pending for the next call)."""

@@ -100,27 +100,42 @@ class Scheduler:
         self.block_manager.deallocate(seq)
         self.waiting.appendleft(seq)
 
-    # --- lookahead form of postprocess for decode steps whose outcome does not depend on the sampled
-    # tokens (every sequence has ignore_eos): `postprocess_early` does everything `postprocess` does except
-    # write the token values, in the same order (hash -> count -> finish/deallocate), so the block manager
-    # goes through exactly the reference's states; `fill_tokens` writes the values once they are on the host.
-    # The engine uses the gap to schedule and stage step N+1 while the GPU still runs step N.
+    # --- lookahead form of postprocess for decode steps: `postprocess_early` does everything `postprocess` does that
+    # cannot depend on the sampled values — hash -> count -> append a PLACEHOLDER -> finish by max_tokens / deallocate —
+    # in the same order, so the block manager goes through the reference's states; `fill_tokens` writes the values
+    # once they are on the host and applies the one thing that DOES depend on them: the EOS test. A sequence that
+    # turns out to have sampled EOS in step N was optimistically scheduled into step N+1 (already enqueued): it is
+    # finished retroactively — its step-N+1 row computes a token nobody reads and stores one K/V row into a block
+    # that is free again (harmless: every later owner writes a slot before reading it; hashed prefix blocks are full
+    # blocks, which that row never touches). The engine uses the gap to schedule and stage step N+1 while the GPU
+    # still runs step N.
     PLACEHOLDER = -1
 
     @staticmethod
     def can_lookahead(seqs: list[Sequence], is_prefill: bool) -> bool:
-        return (not is_prefill) and all(s.ignore_eos for s in seqs)
+        return not is_prefill
 
     def postprocess_early(self, seqs: list[Sequence]) -> None:
-        self.postprocess(seqs, [self.PLACEHOLDER] * len(seqs), False)
+        live = [s for s in seqs if s.status is not SequenceStatus.FINISHED]    # EOS found while this step was in flight
+        self.postprocess(live, [self.PLACEHOLDER] * len(live), False, check_eos=False)
 
-    @staticmethod
-    def fill_tokens(seqs: list[Sequence], token_ids: list[int]) -> None:
+    def fill_tokens(self, seqs: list[Sequence], token_ids: list[int]) -> None:
+        finished = False
         for seq, token_id in zip(seqs, token_ids):
+            if seq.token_ids[-1] != self.PLACEHOLDER:
+                continue                          # finished by EOS one step earlier: this row's result is discarded
             seq.token_ids[-1] = token_id          # the placeholder is still the last element: fill precedes the
             seq.last_token = token_id             # next step's early postprocess
+            if not seq.ignore_eos and token_id == self.eos and seq.status is not SequenceStatus.FINISHED:
+                seq.status = SequenceStatus.FINISHED
+                if seq.block_table:               # (a preempted sequence holds no blocks)
+                    self.block_manager.deallocate(seq)
+                finished = True
+        if finished:
+            self.running = deque(s for s in self.running if s.status is not SequenceStatus.FINISHED)
+            self.waiting = deque(s for s in self.waiting if s.status is not SequenceStatus.FINISHED)
 
-    def postprocess(self, seqs: list[Sequence], token_ids: list[int], is_prefill: bool) -> None:
+    def postprocess(self, seqs: list[Sequence], token_ids: list[int], is_prefill: bool, check_eos: bool = True) -> None:
         bm = self.block_manager
         finished = False
         for seq, token_id in zip(seqs, token_ids):
@@ -130,7 +145,8 @@ class Scheduler:
             if is_prefill and seq.num_cached_tokens < seq.num_tokens:
                 continue                                     # mid-prefill: the sampled token is discarded
             seq.append_token(token_id)
-            if (not seq.ignore_eos and token_id == self.eos) or seq.num_completion_tokens == seq.max_tokens:
+            if (check_eos and not seq.ignore_eos and token_id == self.eos) or \
+                    seq.num_completion_tokens == seq.max_tokens:
                 seq.status = SequenceStatus.FINISHED
                 bm.deallocate(seq)
                 finished = True

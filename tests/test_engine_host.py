@@ -13,6 +13,7 @@ pool small enough to force preemption:
 Plus the rank-0 -> workers control channel (ring of slots in shared memory).
 """
 import os
+import sys
 import threading
 import time
 from random import Random
@@ -180,6 +181,30 @@ def test_staged_block_tables_under_preemption(seed):
     out_b = _generate(_engine(False, **kw), prompts, sps)
     assert out_a == out_b
     assert preempts, "workload must preempt"
+
+
+@pytest.mark.parametrize("seed", range(5))
+def test_lookahead_with_eos_terminated_sequences_equals_serial(seed, monkeypatch):
+    """Sequences WITHOUT ignore_eos: the lookahead enqueues step N+1 before it knows whether step N sampled EOS and
+    finishes such a sequence retroactively. Outputs (tokens and lengths, EOS included as the last token) must equal
+    the strictly serial loop's; more prompts than rows, a tight block pool (preemption) and a 1-in-23 EOS rate."""
+    monkeypatch.setattr(sys.modules[__name__], "VOCAB", 23)
+    r = Random(300 + seed)
+    prompts = [[r.randint(0, 22) for _ in range(r.randint(3, 300))] for _ in range(16)]
+    sps = [SamplingParams(temperature=0.0, ignore_eos=(i % 5 == 4), max_tokens=r.randint(5, 90)) for i in range(16)]
+    kw = dict(max_num_seqs=5, max_model_len=1024, num_kvcache_blocks=9, max_num_batched_tokens=400)
+    outs = {}
+    for mode in (True, False):
+        eng = _engine(mode, **kw)
+        eng.scheduler.eos = 7
+        outs[mode] = _generate(eng, prompts, sps)
+        assert eng.scheduler.block_manager.num_free == 9, "every block returned"
+    assert outs[True] == outs[False]
+    stopped = [t for t, sp in zip(outs[True], sps) if not sp.ignore_eos and len(t) < sp.max_tokens]
+    assert stopped and all(t[-1] == 7 and 7 not in t[:-1] for t in stopped), "some sequences must stop at EOS"
+    for t, sp in zip(outs[True], sps):
+        if sp.ignore_eos:
+            assert len(t) == sp.max_tokens
 
 
 def test_row_cache_is_refreshed_when_a_sequence_returns_with_other_blocks():
