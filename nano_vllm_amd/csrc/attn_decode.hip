@@ -486,43 +486,15 @@ __global__ __launch_bounds__(256, G == 4 ? 2 : 1) void decode_stream_fp8_kernel(
     }
     const int len_cached = FUSED ? len - 1 : len;
 
-    // A 32-token fp8 tile is only 8 KiB per wave; the bf16 kernel keeps 16 KiB in flight. With G <= 2 there are
-    // registers for TWO tiles: load both (16 loads), then consume both.
-    constexpr bool kPair = G <= 2;
+    // (Loading TWO tiles — 16 KiB per wave, what the bf16 kernel keeps in flight — before consuming them was
+    // measured and dropped: 59.3 vs 57.1 us per launch on the bench schedule, profiles/r02_bench_fp8kv_pair_tiles_rejected.json;
+    // at 8 bytes of conversion + FMA work per loaded byte this kernel is no longer waiting on the loads.)
     auto tile_base = [&](int ti) {
       const int t = ti * kTile;
       const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
       return (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;
     };
     int ti = t0;
-    if constexpr (kPair) {
-      u32x4_t kd2[kLoads8], vd2[kLoads8];
-      for (; ti + 1 < t0 + run; ti += 2) {
-        const int64_t b0 = tile_base(ti), b1 = tile_base(ti + 1);
-#pragma unroll
-        for (int i = 0; i < kLoads8; ++i)
-          kd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kc + b0 + i * 8 * 128));
-#pragma unroll
-        for (int i = 0; i < kLoads8; ++i)
-          vd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vc + b0 + i * 8 * 128));
-#pragma unroll
-        for (int i = 0; i < kLoads8; ++i)
-          kd2[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kc + b1 + i * 8 * 128));
-#pragma unroll
-        for (int i = 0; i < kLoads8; ++i)
-          vd2[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vc + b1 + i * 8 * 128));
-        __builtin_amdgcn_sched_barrier(0);  // all 16 loads in flight before the first use
-        const int ta = ti * kTile;
-        consume([&](int i) { return (ta + i * 8 + r8) < len_cached; });
-#pragma unroll
-        for (int i = 0; i < kLoads8; ++i) {
-          kd[i] = kd2[i];
-          vd[i] = vd2[i];
-        }
-        const int tb = ta + kTile;
-        consume([&](int i) { return (tb + i * 8 + r8) < len_cached; });
-      }
-    }
     for (; ti < t0 + run; ++ti) {
       const int t = ti * kTile;
       const int64_t base = tile_base(ti);

@@ -53,6 +53,8 @@ pmcprefill)
   (cd /tmp && rocprofv3 -L > $OUT/rocprof_counters.txt 2>&1; grep -c . $OUT/rocprof_counters.txt; grep -o -E "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*|SQ_LDS_BANK_CONFLICT|SQ_LDS_IDX_ACTIVE|SQ_INSTS_VALU\b|SQ_WAVE_CYCLES|SQ_BUSY_CYCLES|SQ_BUSY_CU_CYCLES" $OUT/rocprof_counters.txt | sort -u | tr '\n' ' '; echo
    timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_prefill -o pf -- python $REPO/tools/prefill_bench.py > $OUT/prefill_under_pmc.json 2> $OUT/prefill_pmc.err; echo "pmcprefill rc=$?"; tail -c 500 $OUT/prefill_pmc.err)
   f=$(find /tmp/pmc_prefill -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_prefill_summary.py $f $OUT/prefill_pmc_summary.json && cat $OUT/prefill_pmc_summary.json;;
+p2pbench)
+  for w in 2 4; do timeout 300 python tools/p2p_bench.py $w > $OUT/p2p_bench_w$w.json 2> $OUT/p2p_bench_w$w.err; echo "p2pbench w=$w rc=$?"; tail -c 300 $OUT/p2p_bench_w$w.err; cat $OUT/p2p_bench_w$w.json; done;;
 replay)
   timeout 600 python tools/attn_replay.py --fused > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
 *) echo "unknown step $w";;
