@@ -241,20 +241,20 @@ def tp_extra(args, torch, dist, rank, world, primary) -> dict | None:
     import threading
     a = copy.copy(args)
     a.model, a.steps, a.warmup, a.no_roofline, a.no_cpu_baseline = "qwen3-32b", 1, 0, True, True
-    if rank == 0:
-        def bail():
+
+    def bail():                       # every rank: a hung collective must not outlive the primary measurement
+        if rank == 0:
             primary["tp_qwen3_32b"] = {"error": "timed out"}
             print(json.dumps(primary), flush=True)
-            os._exit(0)
-        watchdog = threading.Timer(float(os.environ.get("NVL_BENCH_TP_EXTRA_TIMEOUT", "900")), bail)
-        watchdog.daemon = True
-        watchdog.start()
+        os._exit(0)
+    watchdog = threading.Timer(float(os.environ.get("NVL_BENCH_TP_EXTRA_TIMEOUT", "900")) + (0 if rank == 0 else 5), bail)
+    watchdog.daemon = True
+    watchdog.start()
     try:
         r = run_tp_external(a, torch, dist, rank, world, world)
     except Exception as ex:  # noqa: BLE001 — a secondary measurement must never sink the bench line
         r = {"error": repr(ex)}
-    if rank == 0:
-        watchdog.cancel()
+    watchdog.cancel()
     return r
 
 
@@ -439,7 +439,7 @@ def pmc_traffic(alg_bytes_per_launch: float, model: str = "qwen3-0.6b"):
 
 def cpu_baseline(torch, llm, model_name, prompts, out_lens) -> dict:
     """The CPU oracle (a port of the reference's path: oracle/engine.py + oracle/model.py) on a
-    bounded sample: the first 8 sequences of the same seeded stream, outputs capped at 16 tokens."""
+    bounded sample: the first 16 sequences of the same seeded stream, outputs capped at 8 tokens."""
     from nano_vllm_amd.weights import parameter_shapes, qwen3_config_dict, synth_tensor
     from oracle.engine import OracleEngine
     from oracle.model import OracleQwen3
@@ -447,9 +447,9 @@ def cpu_baseline(torch, llm, model_name, prompts, out_lens) -> dict:
     dev = llm.model_runner.device
     weights = {n: synth_tensor(n, s, llm.config.seed, device=dev).cpu() for n, s in parameter_shapes(cfg).items()}
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
+    threads = min(cores, 128)
     torch.set_num_threads(threads)
-    n_seq, cap = 8, 16
+    n_seq, cap = 16, 8               # the first 16 sequences of the seeded stream; outputs capped (bounded run)
     sample_p = prompts[:n_seq]
     sample_o = [min(m, cap) for m in out_lens[:n_seq]]
     eng = OracleEngine(OracleQwen3(cfg, weights, compiled=True), num_blocks=64, block_size=256)
