@@ -325,6 +325,12 @@ int nvl_allreduce_create(int rank, int world, int64_t max_bytes, void** comm_out
 int nvl_allreduce_uid(void* comm, void* uid_out_64B);
 int nvl_allreduce_connect(void* comm, const void* uids);
 int64_t nvl_allreduce_max_bytes(void* comm);
+/* This rank's shared input region (device pointer, nvl_allreduce_max_bytes long): a producer that writes its
+ * [rows, hidden] partial sums THERE (the row-parallel GEMM's output) and passes the same pointer as `in` /
+ * `x_partial` saves the kernel its copy-in phase. set_fences(0) selects the lean hand-off (per-wave store drains
+ * instead of system-scope fences: sufficient because the shared buffer is uncached; default 1). */
+void* nvl_allreduce_buffer(void* comm);
+int nvl_allreduce_set_fences(void* comm, int on);
 int nvl_allreduce_run(void* comm, const void* in, void* out, int64_t rows, int hidden, void* stream);
 int nvl_allreduce_add_rmsnorm(void* comm, const void* x_partial, void* residual, const void* weight,
                               void* y, int64_t rows, int hidden, float eps, void* stream);

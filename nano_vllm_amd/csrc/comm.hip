@@ -51,6 +51,7 @@ struct CommDev {                                // passed by value to the kernel
   unsigned char* base[kMaxWorld];
   int rank, world;
   uint64_t data_off, red_off;
+  int fences;                                   // 1: system-scope release / acquire around every hand-off (default)
 };
 
 struct Comm {                                   // host-side object behind the opaque handle
@@ -72,11 +73,15 @@ __device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) {
 constexpr uint32_t kSpinLimit = 40u * 1000u * 1000u;
 
 // Every thread of the workgroup calls both. `which` = 0 / 1 selects flag0 / flag1.
+// c.fences == 0 ("lean", NVL_TP_P2P_FENCES=0): everything a peer reads lives in UNCACHED memory, so a store that has
+// been acknowledged (vmcnt) is in memory and a load cannot hit a stale line: the per-wave drain + barrier orders
+// payload before flag without the L2 write-back / invalidate a system-scope fence performs (~1.7 us each, four per
+// call). The fenced form stays the default until the lean one has been validated over real xGMI links.
 __device__ __forceinline__ void publish(const CommDev& c, int b, int which, uint32_t epoch) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its own stores
   __syncthreads();
   if (threadIdx.x < 64) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // system scope
+    if (c.fences) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");   // system scope
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the fence's own wait)
     if ((int)threadIdx.x < c.world) {
       Flags* f = reinterpret_cast<Flags*>(c.base[threadIdx.x]);
@@ -99,7 +104,8 @@ __device__ __forceinline__ void await(const CommDev& c, int b, int which, uint32
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (c.fences) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the poll's loads have returned before anyone reads on
   }
   __syncthreads();
 }
@@ -120,9 +126,10 @@ __global__ __launch_bounds__(256) void allreduce_rows_kernel(CommDev c, const bf
   const int nchunks = hidden >> 3;                         // 16-byte chunks per row
   const int slice = nchunks / c.world;                     // chunks per owner column slice
 
-  // ---- phase 0: my rows of the local partial sums -> my shared data region ---------------------------------
-  {
-    bf16_t* data = reinterpret_cast<bf16_t*>(c.base[c.rank] + c.data_off);
+  // ---- phase 0: my rows of the local partial sums -> my shared data region (skipped when the producer — the
+  //      row-parallel GEMM — already wrote them there: nvl_allreduce_buffer) ----------------------------------------
+  bf16_t* data = reinterpret_cast<bf16_t*>(c.base[c.rank] + c.data_off);
+  if (in != data) {
     for (int row = b; row < rows; row += nb)
       for (int ch = tid; ch < nchunks; ch += 256) {
         const int64_t at = (int64_t)row * hidden + ch * 8;
@@ -279,6 +286,7 @@ extern "C" int nvl_allreduce_create(int rank, int world, int64_t max_bytes, void
   cm->dev.world = world;
   cm->dev.data_off = kFlagBytes;
   cm->dev.red_off = kFlagBytes + data;
+  cm->dev.fences = 1;
   void* p = nullptr;
   if (hipExtMallocWithFlags(&p, cm->total_bytes, hipDeviceMallocUncached) != hipSuccess || !p) {
     (void)hipGetLastError();
@@ -336,6 +344,18 @@ extern "C" int nvl_allreduce_connect(void* comm, const void* uids) {
 extern "C" int64_t nvl_allreduce_max_bytes(void* comm) {
   Comm* cm = as_comm(comm);
   return cm ? (int64_t)cm->data_bytes : 0;
+}
+
+extern "C" void* nvl_allreduce_buffer(void* comm) {
+  Comm* cm = as_comm(comm);
+  return cm ? (void*)(cm->dev.base[cm->dev.rank] + cm->dev.data_off) : nullptr;
+}
+
+extern "C" int nvl_allreduce_set_fences(void* comm, int on) {
+  Comm* cm = as_comm(comm);
+  NVL_REQUIRE(cm, "nvl_allreduce_set_fences: null pointer");
+  cm->dev.fences = on ? 1 : 0;
+  return NVL_OK;
 }
 
 extern "C" int nvl_allreduce_run(void* comm, const void* in, void* out, int64_t rows, int hidden, void* stream) {

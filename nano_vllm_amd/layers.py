@@ -401,7 +401,14 @@ class RowParallelLinear(LinearBase):
             return self.forward(x)
         c = tp.comm()
         if c is not None and self.bias is None and x.dim() == 2 and c.fits(x.shape[0], n):
-            return PartialSum(LinearBase.forward(self, x))
+            # the GEMM writes its partial sums straight into this rank's shared comm region: the all-reduce kernel
+            # then starts at its first flag instead of a copy-in phase
+            buf = c.input_buffer(x.shape[0], n, x.device)
+            if _decode_sized(x) and ops.linear_decode_splits(x.shape[0], n, k, ops.LINEAR_BF16):
+                ops.linear_decode(x, self.weight, ops.LINEAR_BF16, out=buf)
+            else:
+                torch.mm(x, self.weight.t(), out=buf)
+            return PartialSum(buf)
         return self.forward(x)
 
 

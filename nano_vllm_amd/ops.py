@@ -59,6 +59,8 @@ SIGNATURES = {
     "nvl_allreduce_uid": (c_int, [c_void_p, c_void_p]),
     "nvl_allreduce_connect": (c_int, [c_void_p, c_void_p]),
     "nvl_allreduce_max_bytes": (c_int64, [c_void_p]),
+    "nvl_allreduce_buffer": (c_void_p, [c_void_p]),
+    "nvl_allreduce_set_fences": (c_int, [c_void_p, c_int]),
     "nvl_allreduce_run": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "nvl_allreduce_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float,
                                           c_void_p]),
@@ -431,6 +433,24 @@ class P2PComm:
         _check(lib().nvl_allreduce_connect(self._h, blob))
         barrier()
         self.max_bytes = int(lib().nvl_allreduce_max_bytes(self._h))
+        if os.environ.get("NVL_TP_P2P_FENCES", "1") == "0":
+            _check(lib().nvl_allreduce_set_fences(self._h, 0))
+        self._views: dict[tuple, torch.Tensor] = {}
+
+    def input_buffer(self, rows: int, hidden: int, device) -> torch.Tensor:
+        """A [rows, hidden] bf16 tensor that IS this rank's shared input region: a GEMM that writes its output
+        here hands it to `all_reduce*` without the kernel's copy-in phase."""
+        key = (rows, hidden)
+        t = self._views.get(key)
+        if t is None:
+            assert rows * hidden * 2 <= self.max_bytes
+            ptr = int(lib().nvl_allreduce_buffer(self._h))
+
+            class _Region:                      # torch wraps foreign device memory through the CUDA array interface
+                __cuda_array_interface__ = {"shape": (rows * hidden,), "typestr": "<i2", "data": (ptr, False), "version": 2}
+            t = torch.as_tensor(_Region(), device=device).view(torch.bfloat16).view(rows, hidden)
+            self._views[key] = t
+        return t
 
     def fits(self, rows: int, hidden: int) -> bool:
         return rows * hidden * 2 <= self.max_bytes and hidden % (8 * self.world) == 0 and hidden <= 8192

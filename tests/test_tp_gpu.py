@@ -81,6 +81,30 @@ def _comm_worker(rank, world, port, q):
             errs[f"res_{rows}x{hid}"] = float((res_d.cpu().float() - s.to(torch.bfloat16).float()).abs().max())
             errs[f"norm_ulp_{rows}x{hid}"] = int(bf16_ulp_diff(y.cpu(), yref).max())
             calls += 2
+        # zero-copy input (the GEMM writes its partial sums straight into the shared region) and the lean hand-off
+        # (store drains instead of system-scope fences: the region is uncached), all four combinations
+        for lean in (0, 1):
+            ops.lib().nvl_allreduce_set_fences(comm._h, 0 if lean else 1)
+            dist.barrier()
+            for it, (rows, hid) in enumerate([(131, 5120), (2, 5120), (64, 4096)]):
+                if hid % (8 * world):
+                    continue
+                parts = [part(r, rows, hid, 50 + it) for r in range(world)]
+                acc = torch.zeros(rows, hid)
+                for p in parts:
+                    acc += p.float()
+                exact = acc.to(torch.bfloat16)
+                buf = comm.input_buffer(rows, hid, dev)
+                buf.copy_(parts[rank])
+                got = comm.all_reduce(buf, out=torch.empty(rows, hid, dtype=torch.bfloat16, device=dev))
+                errs[f"zero_copy_lean{lean}_{rows}x{hid}"] = float((got.cpu().float() - exact.float()).abs().max())
+                x2 = torch.mm(parts[rank].to(dev), torch.eye(hid, dtype=torch.bfloat16, device=dev), out=buf)   # a GEMM as producer
+                res = torch.zeros(rows, hid, dtype=torch.bfloat16, device=dev)
+                w1 = torch.ones(hid, dtype=torch.bfloat16, device=dev)
+                comm.all_reduce_add_rmsnorm(x2, res, w1, 1e-6)
+                errs[f"zero_copy_norm_lean{lean}_{rows}x{hid}"] = float((res.cpu().float() - exact.float()).abs().max())
+        ops.lib().nvl_allreduce_set_fences(comm._h, 1)
+        dist.barrier()
         # small all-gather (the sampler's winners): 512 rows x 8 bytes
         mine = torch.full((512, 2), rank + 1, dtype=torch.int32, device=dev)
         mine[:, 1] = torch.arange(512, dtype=torch.int32, device=dev) * (rank + 1)

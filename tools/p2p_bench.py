@@ -22,15 +22,20 @@ def worker(rank, world, port, q):
 
     comm = ops.P2PComm(rank, world, 256 * 5120 * 2, exchange, dist.barrier)
     res = {}
-    for rows, hid in ((1, 5120), (16, 5120), (131, 5120), (256, 5120), (131, 4096)):
+    for rows, hid, lean, zero_copy in [(r_, h_, l_, z_) for (r_, h_) in ((1, 5120), (16, 5120), (131, 5120), (256, 5120), (131, 4096))
+                                       for l_ in (0, 1) for z_ in (0, 1)]:
         if hid % (8 * world):
             continue
-        x = torch.randn(rows, hid, device="cuda").to(torch.bfloat16)
+        ops.lib().nvl_allreduce_set_fences(comm._h, 0 if lean else 1)
+        dist.barrier()
+        x = comm.input_buffer(rows, hid, torch.device("cuda", 0)) if zero_copy else torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16)
+        x.copy_(torch.randn(rows, hid, device="cuda").to(torch.bfloat16))
         r = torch.randn(rows, hid, device="cuda").to(torch.bfloat16)
         w = torch.ones(hid, device="cuda", dtype=torch.bfloat16)
-        y = torch.empty_like(x)
-        for name, fn in (("allreduce", lambda: comm.all_reduce(x, out=y)),
-                         ("allreduce_add_rmsnorm", lambda: comm.all_reduce_add_rmsnorm(x, r, w, 1e-6, out=y))):
+        y = torch.empty(rows, hid, device="cuda", dtype=torch.bfloat16)
+        tag = ("lean" if lean else "fenced") + ("+zero_copy" if zero_copy else "")
+        for name, fn in ((f"allreduce[{tag}]", lambda: comm.all_reduce(x, out=y)),
+                         (f"allreduce_add_rmsnorm[{tag}]", lambda: comm.all_reduce_add_rmsnorm(x, r, w, 1e-6, out=y))):
             fn(); torch.cuda.synchronize(); dist.barrier()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
