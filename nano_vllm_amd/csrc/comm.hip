@@ -73,10 +73,12 @@ __device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) {
 constexpr uint32_t kSpinLimit = 40u * 1000u * 1000u;
 
 // Every thread of the workgroup calls both. `which` = 0 / 1 selects flag0 / flag1.
-// c.fences == 0 ("lean", NVL_TP_P2P_FENCES=0): everything a peer reads lives in UNCACHED memory, so a store that has
-// been acknowledged (vmcnt) is in memory and a load cannot hit a stale line: the per-wave drain + barrier orders
-// payload before flag without the L2 write-back / invalidate a system-scope fence performs (~1.7 us each, four per
-// call). The fenced form stays the default until the lean one has been validated over real xGMI links.
+// c.fences == 0 ("lean", what the engine selects; NVL_TP_P2P_FENCES=1 restores the fences): everything a peer reads
+// lives in UNCACHED memory, so a store that has been acknowledged (vmcnt) is in memory and a load cannot hit a stale
+// line: the per-wave drain + barrier orders payload before flag — the "write-through payload -> vmcnt(0) -> flag" form
+// of Guideline 16 (R1) — without the L2 write-back / invalidate of a system-scope fence, four of which per call were
+// most of the protocol cost (131 x 5120, 2 ranks on one GPU: 14.7 -> 10.4 us; with the producer GEMM writing into the
+// shared region, 8.7 us; profiles/r02_p2p_bench_w2.json). Exactness tests run both flavours (tests/test_tp_gpu.py).
 __device__ __forceinline__ void publish(const CommDev& c, int b, int which, uint32_t epoch) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every storing wave drains its own stores
   __syncthreads();
@@ -286,7 +288,7 @@ extern "C" int nvl_allreduce_create(int rank, int world, int64_t max_bytes, void
   cm->dev.world = world;
   cm->dev.data_off = kFlagBytes;
   cm->dev.red_off = kFlagBytes + data;
-  cm->dev.fences = 1;
+  cm->dev.fences = 1;      // library default: fenced; the engine (ops.P2PComm) selects the lean form
   void* p = nullptr;
   if (hipExtMallocWithFlags(&p, cm->total_bytes, hipDeviceMallocUncached) != hipSuccess || !p) {
     (void)hipGetLastError();

@@ -433,8 +433,10 @@ class P2PComm:
         _check(lib().nvl_allreduce_connect(self._h, blob))
         barrier()
         self.max_bytes = int(lib().nvl_allreduce_max_bytes(self._h))
-        if os.environ.get("NVL_TP_P2P_FENCES", "1") == "0":
-            _check(lib().nvl_allreduce_set_fences(self._h, 0))
+        # Hand-off flavour: lean by default (per-wave store drains; the shared buffer is uncached, so an acknowledged
+        # store is in memory and a load cannot hit a stale line); NVL_TP_P2P_FENCES=1 adds the system-scope
+        # release / acquire fences back (14.7 -> 8.7 us per 131 x 5120 all-reduce without them, profiles/r02_p2p_bench_w2.json)
+        _check(lib().nvl_allreduce_set_fences(self._h, 1 if os.environ.get("NVL_TP_P2P_FENCES", "0") == "1" else 0))
         self._views: dict[tuple, torch.Tensor] = {}
 
     def input_buffer(self, rows: int, hidden: int, device) -> torch.Tensor:
