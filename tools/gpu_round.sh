@@ -55,6 +55,14 @@ pmcprefill)
   f=$(find /tmp/pmc_prefill -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_prefill_summary.py $f $OUT/prefill_pmc_summary.json && cat $OUT/prefill_pmc_summary.json;;
 p2pbench)
   for w in 2 4; do timeout 300 python tools/p2p_bench.py $w > $OUT/p2p_bench_w$w.json 2> $OUT/p2p_bench_w$w.err; echo "p2pbench w=$w rc=$?"; tail -c 300 $OUT/p2p_bench_w$w.err; cat $OUT/p2p_bench_w$w.json; done;;
+tprun)
+  # what the driver runs for N = 2 (python -m torch.distributed.run ... bench.py --gpus 2), with both ranks on the ONE GPU
+  # (functional: NVL_BENCH_SHARE_GPU=1 + gloo). (a) default model: 2 data-parallel replicas + the Qwen3-32B TP=2 extra;
+  # (b) --tp 2 as the primary metric on Qwen3-0.6B shapes.
+  export NVL_BENCH_SHARE_GPU=1 NVL_BENCH_BACKEND=gloo
+  timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 0 --num-seqs 48 --gpu-memory-utilization 0.3 --num-kvcache-blocks 300 --no-cpu-baseline --no-roofline > $OUT/torchrun_dp2_plus_tp_extra.json 2> $OUT/torchrun_dp2.err; echo "torchrun dp2+extra rc=$?"; grep -v "socket.cpp\|Gloo\|amdgpu.ids" $OUT/torchrun_dp2.err | tail -15; cat $OUT/torchrun_dp2_plus_tp_extra.json
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --tp 2 --steps 1 --warmup 0 --num-seqs 48 --num-kvcache-blocks 300 --no-cpu-baseline > $OUT/torchrun_tp2_qwen3-0.6b.json 2> $OUT/torchrun_tp2.err; echo "torchrun tp2 rc=$?"; grep -v "socket.cpp\|Gloo\|amdgpu.ids" $OUT/torchrun_tp2.err | tail -15; cat $OUT/torchrun_tp2_qwen3-0.6b.json
+  unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND;;
 replay)
   timeout 600 python tools/attn_replay.py --fused > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
 *) echo "unknown step $w";;
