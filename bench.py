@@ -230,7 +230,12 @@ def run_tp_external(args, torch, dist, rank, world, tp):
     result = base_result(args, tp, 1, world, elapsed, total_out, llm,
                          f"tp{tp} (one engine, tensor-parallel over {tp} GPUs: xGMI P2P all-reduce "
                          f"{'on' if llm.model_runner.p2p else 'OFF (process-group fallback)'})")
-    llm.exit()
+    try:
+        llm.exit()
+        result["config"]["p2p_status"] = "ok" if result["config"]["parallelism"].find("all-reduce on") >= 0 else "n/a"
+    except Exception as ex:  # noqa: BLE001 — a latched collective timeout invalidates the number but must be REPORTED
+        result["config"]["p2p_status"] = repr(ex)
+        result["value"] = None
     return result
 
 

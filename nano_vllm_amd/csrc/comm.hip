@@ -19,7 +19,8 @@
 //   phase 2  workgroup b waits for flag1[b][*] and assembles its full rows from the W owners' `reduced` regions;
 //            epilogue = plain store, or the reference's add_rms_forward (layers/layernorm.py:28-40: residual add
 //            + RMSNorm) so the all-reduce and the norm that always follows it are ONE launch.
-//   One-shot (tiny messages): phase 1 is skipped and phase 2 sums the peers' `data` rows directly.
+//   One-shot (tiny messages): phase 1 is skipped and phase 2 sums the peers' `data` rows directly; a closing flag1
+//            exchange then tells every rank that all peers are done reading its rows.
 // Re-use safety: a rank overwrites `data` in call e+1 only after its kernel of call e has completed, i.e. after
 // every one of its workgroups has seen flag1 = e from every peer, which peers publish after their phase-1 reads;
 // it overwrites `reduced` rows in phase 1 of call e+1 only after flag0 = e+1 from every peer, which a peer
@@ -68,8 +69,8 @@ __device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// ~4 s at 2 GHz with the s_sleep below: generous, because two ranks may be time-sliced on ONE GPU in the
-// single-GPU functional test; on a healthy 8-GPU node a wait is microseconds.
+// Tens of seconds with the s_sleep below: generous, because several ranks may be time-sliced on ONE GPU in the
+// single-GPU functional tests; on a healthy 8-GPU node a wait is microseconds.
 constexpr uint32_t kSpinLimit = 40u * 1000u * 1000u;
 
 // Every thread of the workgroup calls both. `which` = 0 / 1 selects flag0 / flag1.
@@ -218,6 +219,13 @@ __global__ __launch_bounds__(256) void allreduce_rows_kernel(CommDev c, const bf
         }
       }
     }
+  }
+  if constexpr (ONESHOT) {
+    // One-shot has no second exchange of its own, so nothing yet says "every peer has finished reading my rows":
+    // without this hand-shake a fast rank's NEXT producer (the GEMM writing into its shared region, or the next
+    // call's copy-in) could overwrite rows a slower peer is still summing.
+    publish(c, b, 1, epoch);
+    await(c, b, 1, epoch);
   }
   if (tid == 0) st_sys(&mine->epoch[b], epoch);
 }

@@ -299,8 +299,12 @@ class ModelRunner:
         torch.cuda.synchronize()
         if self.world_size > 1:
             from .. import tp
+            problem = None
             if self.p2p:
-                tp.comm().status()            # raises if any P2P collective ever timed out waiting for a peer
+                try:
+                    tp.comm().status()        # did any P2P collective ever give up waiting for a peer?
+                except ops.NvlError as ex:
+                    problem = ex
             dist.barrier()
             if self.chan is not None:
                 self.chan.close()
@@ -308,6 +312,8 @@ class ModelRunner:
             tp.shutdown()
             if self._own_pg:
                 dist.destroy_process_group()
+            if problem is not None:           # after the clean-up, so the other ranks are not left in a barrier
+                raise problem
 
     def loop(self):
         """Worker ranks: execute the steps rank 0 posts (model_runner.py:61-74)."""

@@ -63,6 +63,13 @@ tprun)
   timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 0 --num-seqs 48 --gpu-memory-utilization 0.3 --num-kvcache-blocks 300 --no-cpu-baseline --no-roofline > $OUT/torchrun_dp2_plus_tp_extra.json 2> $OUT/torchrun_dp2.err; echo "torchrun dp2+extra rc=$?"; grep -v "socket.cpp\|Gloo\|amdgpu.ids" $OUT/torchrun_dp2.err | tail -15; cat $OUT/torchrun_dp2_plus_tp_extra.json
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29534 bench.py --gpus 2 --tp 2 --steps 1 --warmup 0 --num-seqs 48 --num-kvcache-blocks 300 --no-cpu-baseline > $OUT/torchrun_tp2_qwen3-0.6b.json 2> $OUT/torchrun_tp2.err; echo "torchrun tp2 rc=$?"; grep -v "socket.cpp\|Gloo\|amdgpu.ids" $OUT/torchrun_tp2.err | tail -15; cat $OUT/torchrun_tp2_qwen3-0.6b.json
   unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND;;
+tprun2)
+  export NVL_BENCH_SHARE_GPU=1 NVL_BENCH_BACKEND=gloo
+  for v in "lean" "fenced"; do
+    if [ $v = fenced ]; then export NVL_TP_P2P_FENCES=1; else unset NVL_TP_P2P_FENCES; fi
+    /usr/bin/time -f "wall %e s" timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 2 --tp 2 --steps 1 --warmup 0 --num-seqs 48 --num-kvcache-blocks 300 --no-cpu-baseline > $OUT/torchrun_tp2_$v.json 2> $OUT/torchrun_tp2_$v.err; echo "torchrun tp2 $v rc=$?"; grep -v "socket.cpp\|Gloo\|amdgpu.ids\|OMP_NUM\|\*\*\*" $OUT/torchrun_tp2_$v.err | tail -6; cut -c1-700 $OUT/torchrun_tp2_$v.json; echo
+  done
+  unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND NVL_TP_P2P_FENCES;;
 replay)
   timeout 600 python tools/attn_replay.py --fused > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
 *) echo "unknown step $w";;
