@@ -81,6 +81,11 @@ class _Channel:
             while True:
                 try:
                     self.shm = SharedMemory(name=name)
+                    try:                                   # attached, not owned: rank 0 unlinks it — keep Python's
+                        from multiprocessing import resource_tracker      # tracker from "cleaning up" a segment that
+                        resource_tracker.unregister(self.shm._name, "shared_memory")   # is not this process' to remove
+                    except Exception:  # noqa: BLE001
+                        pass
                     break
                 except FileNotFoundError:
                     if time.time() > deadline:
