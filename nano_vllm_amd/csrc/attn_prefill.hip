@@ -25,7 +25,8 @@
 
 namespace {
 
-constexpr int kQBlk = 128;   // query rows per workgroup (4 waves x 32)
+constexpr int kQBlk = 128;   // query rows per workgroup (4 waves x 32; with 8 waves: of two q-heads)
+constexpr int kDefaultWaves = 4;   // NVL_PREFILL_WAVES overrides (A/B in profiles/r02_prefill_waves{4,8}.json)
 constexpr int kKBlk = 64;    // keys per tile
 constexpr int kKRowB = 256;  // K tile row bytes in LDS
 constexpr int kVRowB = 320;  // V tile row bytes in LDS (256 + 64 pad: conflict-free tr reads)
@@ -44,25 +45,32 @@ constexpr int kTileBytes = kKBlk * (kKRowB + kVRowB);   // one K + V tile pair i
 
 // KV8 (PAGED only): the cache holds OCP fp8 e4m3 (128 bytes per (token, head) row); a staged tile is converted to
 // bf16 on its way into LDS (exact), everything downstream is unchanged.
-template <bool PAGED, bool KV8>
-__global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
+// NW = 4: one workgroup = 4 waves = 128 query rows of ONE q-head (two such workgroups per CU).
+// NW = 8: one workgroup = 8 waves = the same 128 query rows of TWO q-heads of one kv group (waves 0-3 / 4-7): the
+//         K/V tile is fetched from L2/HBM and written to LDS once for both heads — half the staging loads, LDS
+//         writes and prologue work per MFMA, at the price of an 8-wave barrier domain (one workgroup per CU).
+template <bool PAGED, bool KV8, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_tok_stride,
     int64_t v_tok_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int num_seqs, int hq,
     int hkv, int block_size, float scale_log2e, int xcd_map) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // two {K: 64 x 256 B, V: 64 x 320 B} tile buffers, then the tile-lookup scratch
+  constexpr int NT = NW * 64;                            // threads per workgroup
   int* wsum = reinterpret_cast<int*>(smem + 2 * kTileBytes);
-  int* pre = wsum + 4;                                  // [num_seqs + 1]
+  int* pre = wsum + 8;                                  // [num_seqs + 1]
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
+  const int wave = wave_all & 3;                        // 32-row block of the 128-row q tile
+  const int hsub = wave_all >> 2;                       // which of the workgroup's q-heads (NW == 8)
   const int qcol = lane & 31, hi = lane >> 5;
 
   // ---- which (sequence, q-block) is this workgroup? ------------------------------------
   {
     int carry = 0;
     if (tid == 0) pre[0] = 0;
-    for (int base = 0; base < num_seqs; base += 256) {
+    for (int base = 0; base < num_seqs; base += NT) {
       const int i = base + tid;
       int val = 0;
       if (i < num_seqs) val = (cu_q[i + 1] - cu_q[i] + kQBlk - 1) / kQBlk;
@@ -72,13 +80,13 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
         const int n = __shfl_up(s, o, 64);
         if (lane >= o) s += n;
       }
-      if (lane == 63) wsum[wave] = s;
+      if (lane == 63) wsum[wave_all] = s;
       __syncthreads();
       int woff = 0, tot = 0;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < NW; ++w) {
         const int t = wsum[w];
-        if (w < wave) woff += t;
+        if (w < wave_all) woff += t;
         tot += t;
       }
       if (i < num_seqs) pre[i + 1] = carry + woff + s;
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     tile_rank = j / hkv;
     head = (j - tile_rank * hkv) * G + g;
   } else {
-    head = blockIdx.x;
+    head = NW == 8 ? blockIdx.x * 2 + hsub : blockIdx.x;
     tile_rank = blockIdx.y;
   }
   if (tile_rank >= pre[num_seqs]) return;  // grid is an upper bound
@@ -162,12 +170,14 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
   // this thread's chunk n of a tile: row (tid >> 4) + 16 n, 16-byte column tid & 15; element offsets from
   // the tile's first row are loop-invariant (no 64-bit multiplies in the loop)
   const int64_t kstride = PAGED ? 128 : k_tok_stride, vstride = PAGED ? 128 : v_tok_stride;
+  constexpr int kCh = 1024 / NT;                         // 16-byte chunks of a bf16 K (or V) tile per thread
+  constexpr int kCh8 = 512 / NT;                         // ... of an fp8 tile
   const int srow = tid >> 4, sc16 = tid & 15;
   unsigned int koff[4], voff[4];   // BYTE offsets, unsigned: the loads use the SGPR-base + 32-bit VGPR offset form
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    koff[n] = ((unsigned int)((srow + n * 16) * kstride) + sc16 * 8) * 2u;
-    voff[n] = ((unsigned int)((srow + n * 16) * vstride) + sc16 * 8) * 2u;
+  for (int n = 0; n < kCh; ++n) {
+    koff[n] = ((unsigned int)((srow + n * (NT / 16)) * kstride) + sc16 * 8) * 2u;
+    voff[n] = ((unsigned int)((srow + n * (NT / 16)) * vstride) + sc16 * 8) * 2u;
   }
   // Loads go through buffer descriptors (SGPR base + SGPR tile offset + the loop-invariant VGPR byte
   // offsets above): no per-tile address VALU, nothing the loads depend on is rewritten while they are in
@@ -196,15 +206,15 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
       vsoff = (int)(kt * vstride * 2);
     }
     if constexpr (KV8) {
-      // 64 keys x 128 B = 512 16-byte chunks: two per thread (chunk = tid + 256 n -> row chunk >> 3, 16 elements)
+      // 64 keys x 128 B = 512 16-byte chunks (chunk = tid + NT n -> row chunk >> 3, 16 elements)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        kreg[n] = __builtin_amdgcn_raw_buffer_load_b128(krs, (tid + n * 256) * 16, ksoff, 0);
-        vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(vrs, (tid + n * 256) * 16, vsoff, 0);
+      for (int n = 0; n < kCh8; ++n) {
+        kreg[n] = __builtin_amdgcn_raw_buffer_load_b128(krs, (tid + n * NT) * 16, ksoff, 0);
+        vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(vrs, (tid + n * NT) * 16, vsoff, 0);
       }
     } else {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
+      for (int n = 0; n < kCh; ++n) {
         kreg[n] = __builtin_amdgcn_raw_buffer_load_b128(krs, koff[n], ksoff, 0);
         vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[n], vsoff, 0);
       }
@@ -215,8 +225,8 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
     unsigned char* vl = kl + kKBlk * kKRowB;
     if constexpr (KV8) {
 #pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const int chunk = tid + n * 256;
+      for (int n = 0; n < kCh8; ++n) {
+        const int chunk = tid + n * NT;
         const int row = chunk >> 3, c16 = (chunk & 7) * 2;          // two bf16 16-byte chunks per fp8 chunk
         u32x4_t a, b;
         fp8x16_to_bf16(kreg[n], &a, &b);
@@ -228,8 +238,8 @@ __global__ __launch_bounds__(256, 2) void prefill_attn_kernel(
       }
     } else {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) {
-        const int chunk = tid + n * 256;
+      for (int n = 0; n < kCh; ++n) {
+        const int chunk = tid + n * NT;
         const int row = chunk >> 4, c16 = chunk & 15;
         *reinterpret_cast<u32x4_t*>(kl + row * kKRowB + ((c16 ^ (row & 15)) << 4)) = kreg[n];
         *reinterpret_cast<u32x4_t*>(vl + row * kVRowB + (c16 << 4)) = vreg[n];
@@ -385,19 +395,23 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   if (total_q == 0 || num_seqs == 0) return NVL_OK;
   const int64_t tiles = (total_q + kQBlk - 1) / kQBlk + num_seqs;  // upper bound on sum ceil(Lq/128)
   NVL_REQUIRE(tiles < (1ll << 31), "nvl_attn_prefill_varlen: too many query tiles");
-  const size_t lds = (size_t)2 * kTileBytes + 4 * sizeof(int) + (size_t)(num_seqs + 1) * sizeof(int);
+  const size_t lds = (size_t)2 * kTileBytes + 8 * sizeof(int) + (size_t)(num_seqs + 1) * sizeof(int);
   const float sl2 = softmax_scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
   // NVL_PREFILL_XCD=1: XCD-aware workgroup numbering (see the kernel). Off by default — measured A/B on MI355X
   // (profiles/r02_prefill_xcd{0,1}.json): 4 x 4096 +1.5 %, 8 x 2048 / G = 8 +1.5 %, 16 x 1024 +0.7 %, bench-like
   // 29 x 561 -3 %, 1 x 16384 (16 / 8 heads) -12 %: co-locating a group's heads helps less than it hurts the
   // longest-first balance across XCDs.
-  static int xcd_map = -1;
+  // NVL_PREFILL_WAVES=4|8: workgroup shape (see the kernel); 8 needs an even group size Hq / Hkv.
+  static int xcd_map = -1, waves = -1;
   if (xcd_map < 0) {
     const char* e = getenv("NVL_PREFILL_XCD");
     xcd_map = (e && e[0] == '1') ? 1 : 0;
+    const char* w = getenv("NVL_PREFILL_WAVES");
+    waves = (w && w[0] == '8') ? 8 : ((w && w[0] == '4') ? 4 : kDefaultWaves);
   }
-  dim3 grid((unsigned)num_q_heads, (unsigned)tiles);
+  const bool eight = waves == 8 && !xcd_map && (num_q_heads / num_kv_heads) % 2 == 0;
+  dim3 grid((unsigned)(eight ? num_q_heads / 2 : num_q_heads), (unsigned)tiles);
   if (xcd_map) {
     const int64_t groups = tiles * num_kv_heads;
     const int64_t blocks = ((groups + 7) / 8) * 8 * (num_q_heads / num_kv_heads);
@@ -412,29 +426,28 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
     const size_t want = lds < 160 * 1024 ? lds + 16 * 1024 : lds;   // headroom: num_seqs moves it by a few KiB
     const size_t cap = want > 160 * 1024 ? 160 * 1024 : want;
     NVL_REQUIRE(lds <= 160 * 1024, "nvl_attn_prefill_varlen: %d sequences need %zu B of LDS (> 160 KiB)", num_seqs, lds);
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<true, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<true, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<false, false>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess) {
+#define NVL_PF_ATTR(P, K8, NWV)                                                                            \
+    (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<P, K8, NWV>),                  \
+                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess)
+    if (NVL_PF_ATTR(true, false, 4) || NVL_PF_ATTR(true, true, 4) || NVL_PF_ATTR(false, false, 4) ||
+        NVL_PF_ATTR(true, false, 8) || NVL_PF_ATTR(true, true, 8) || NVL_PF_ATTR(false, false, 8)) {
       nvl_set_error("nvl_attn_prefill_varlen: cannot reserve %zu B of LDS", cap);
       return NVL_ELAUNCH;
     }
+#undef NVL_PF_ATTR
     lds_cap = cap;
   }
+#define NVL_PF_LAUNCH(P, K8, NWV)                                                                                      \
+  hipLaunchKernelGGL((prefill_attn_kernel<P, K8, NWV>), grid, dim3(NWV * 64), lds, s, (const bf16_t*)q,                 \
+                     (const bf16_t*)k, (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k,        \
+                     block_tables, bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map)
   if (paged && kv_dtype == NVL_KV_FP8) {
-    hipLaunchKernelGGL((prefill_attn_kernel<true, true>), grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables,
-                       bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map);
+    if (eight) NVL_PF_LAUNCH(true, true, 8); else NVL_PF_LAUNCH(true, true, 4);
   } else if (paged) {
-    hipLaunchKernelGGL((prefill_attn_kernel<true, false>), grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables,
-                       bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map);
+    if (eight) NVL_PF_LAUNCH(true, false, 8); else NVL_PF_LAUNCH(true, false, 4);
   } else {
-    hipLaunchKernelGGL((prefill_attn_kernel<false, false>), grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables,
-                       bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map);
+    if (eight) NVL_PF_LAUNCH(false, false, 8); else NVL_PF_LAUNCH(false, false, 4);
   }
+#undef NVL_PF_LAUNCH
   return nvl_check_launch("nvl_attn_prefill_varlen");
 }

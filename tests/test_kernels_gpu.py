@@ -6,6 +6,7 @@ the compiled reference rounds (rotary and KV store are bit-exact); attention max
 <= 2e-2 * absmax (flash tolerance; P is rounded to bf16 before P.V in both).
 """
 import math
+import os
 
 import pytest
 import torch
@@ -486,6 +487,19 @@ def test_prefill_paged_continuation_of_a_prompt_longer_than_the_token_budget(ops
     o_ref = _oracle_attend_chunked(q.cuda(), ks, vs, scale, lk - lq)
     err = (o.float() - o_ref.float()).abs().max().item()
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+
+
+def test_prefill_other_workgroup_shape_passes_the_same_tests():
+    """The prefill kernel exists in two workgroup shapes (4 waves = one q-head, 8 waves = two q-heads of a kv group
+    sharing the staged K/V tile), selected once per process by NVL_PREFILL_WAVES: run the oracle comparisons of this
+    file once more in a child process with the shape that is NOT this process' default."""
+    import subprocess
+    import sys
+    other = "8" if os.environ.get("NVL_PREFILL_WAVES", "4") != "8" else "4"
+    env = dict(os.environ, NVL_PREFILL_WAVES=other)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "prefill and not other_workgroup_shape"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
 # ------------------------------------------------------------------------------------------

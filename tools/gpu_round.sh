@@ -70,6 +70,9 @@ tprun2)
     T0=$(date +%s); timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 2 --tp 2 --steps 1 --warmup 0 --num-seqs 48 --num-kvcache-blocks 300 --no-cpu-baseline > $OUT/torchrun_tp2_$v.json 2> $OUT/torchrun_tp2_$v.err; echo "torchrun tp2 $v rc=$? wall=$(( $(date +%s) - T0 )) s"; grep -v "socket.cpp\|Gloo\|amdgpu.ids\|OMP_NUM\|\*\*\*" $OUT/torchrun_tp2_$v.err | tail -6; cut -c1-700 $OUT/torchrun_tp2_$v.json; echo
   done
   unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND NVL_TP_P2P_FENCES;;
+prefillw)
+  for w in 4 8; do NVL_PREFILL_WAVES=$w timeout 600 python tools/prefill_bench.py > $OUT/prefill_waves$w.json 2> $OUT/prefill_waves$w.err; echo "prefill waves=$w rc=$?"; cat $OUT/prefill_waves$w.json; echo; done
+  NVL_PREFILL_WAVES=8 timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -k "prefill" 2>&1 | tail -3;;
 replay)
   timeout 600 python tools/attn_replay.py --fused > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
 *) echo "unknown step $w";;
