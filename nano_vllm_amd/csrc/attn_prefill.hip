@@ -26,7 +26,6 @@
 namespace {
 
 constexpr int kQBlk = 128;   // query rows per workgroup (4 waves x 32; with 8 waves: of two q-heads)
-constexpr int kDefaultWaves = 4;   // NVL_PREFILL_WAVES overrides (A/B in profiles/r02_prefill_waves{4,8}.json)
 constexpr int kKBlk = 64;    // keys per tile
 constexpr int kKRowB = 256;  // K tile row bytes in LDS
 constexpr int kVRowB = 320;  // V tile row bytes in LDS (256 + 64 pad: conflict-free tr reads)
@@ -391,7 +390,6 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
                     v_tok_stride >= (int64_t)num_kv_heads * 128,
                 "nvl_attn_prefill_varlen: bad K/V token strides");
   }
-  (void)max_seqlen_q;
   if (total_q == 0 || num_seqs == 0) return NVL_OK;
   const int64_t tiles = (total_q + kQBlk - 1) / kQBlk + num_seqs;  // upper bound on sum ceil(Lq/128)
   NVL_REQUIRE(tiles < (1ll << 31), "nvl_attn_prefill_varlen: too many query tiles");
@@ -402,15 +400,20 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // (profiles/r02_prefill_xcd{0,1}.json): 4 x 4096 +1.5 %, 8 x 2048 / G = 8 +1.5 %, 16 x 1024 +0.7 %, bench-like
   // 29 x 561 -3 %, 1 x 16384 (16 / 8 heads) -12 %: co-locating a group's heads helps less than it hurts the
   // longest-first balance across XCDs.
-  // NVL_PREFILL_WAVES=4|8: workgroup shape (see the kernel); 8 needs an even group size Hq / Hkv.
+  // Workgroup shape (see the kernel): 8 waves (two q-heads share the staged K/V tile) when the launch has long
+  // sequences, 4 waves otherwise — measured (profiles/r02_prefill_waves{4,8}.json, TFLOP/s 4 / 8 waves): 1 x 16384
+  // 908 / 931 (16/8 heads), 819 / 856 (8/1); 4 x 4096 693 / 718; 8 x 2048 G = 8 741 / 743; but 16 x 1024 497 / 422
+  // and 29 x 561 343 / 326: short sequences have too few tiles per workgroup to amortise the 8-wave barrier.
+  // NVL_PREFILL_WAVES=4|8 forces one shape; 8 needs an even group size Hq / Hkv.
   static int xcd_map = -1, waves = -1;
   if (xcd_map < 0) {
     const char* e = getenv("NVL_PREFILL_XCD");
     xcd_map = (e && e[0] == '1') ? 1 : 0;
     const char* w = getenv("NVL_PREFILL_WAVES");
-    waves = (w && w[0] == '8') ? 8 : ((w && w[0] == '4') ? 4 : kDefaultWaves);
+    waves = (w && w[0] == '8') ? 8 : ((w && w[0] == '4') ? 4 : 0);
   }
-  const bool eight = waves == 8 && !xcd_map && (num_q_heads / num_kv_heads) % 2 == 0;
+  const int want = waves ? waves : (max_seqlen_q >= 2048 ? 8 : 4);
+  const bool eight = want == 8 && !xcd_map && (num_q_heads / num_kv_heads) % 2 == 0;
   dim3 grid((unsigned)(eight ? num_q_heads / 2 : num_q_heads), (unsigned)tiles);
   if (xcd_map) {
     const int64_t groups = tiles * num_kv_heads;

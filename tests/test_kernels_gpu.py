@@ -491,12 +491,12 @@ def test_prefill_paged_continuation_of_a_prompt_longer_than_the_token_budget(ops
 
 def test_prefill_other_workgroup_shape_passes_the_same_tests():
     """The prefill kernel exists in two workgroup shapes (4 waves = one q-head, 8 waves = two q-heads of a kv group
-    sharing the staged K/V tile), selected once per process by NVL_PREFILL_WAVES: run the oracle comparisons of this
-    file once more in a child process with the shape that is NOT this process' default."""
+    sharing the staged K/V tile), chosen per launch by max_seqlen_q unless NVL_PREFILL_WAVES forces one: run the oracle
+    comparisons of this file once more in a child process with the 8-wave shape forced for EVERY launch (the default
+    only takes it for long sequences)."""
     import subprocess
     import sys
-    other = "8" if os.environ.get("NVL_PREFILL_WAVES", "4") != "8" else "4"
-    env = dict(os.environ, NVL_PREFILL_WAVES=other)
+    env = dict(os.environ, NVL_PREFILL_WAVES="8")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
                         "prefill and not other_workgroup_shape"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
