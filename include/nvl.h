@@ -35,7 +35,7 @@
  * `kv_dtype` (entry points that touch the cache): NVL_KV_BF16 = the reference's cache
  * precision (every parity run); NVL_KV_FP8 = opt-in OCP fp8 e4m3 cache (128 bytes per row,
  * K/V rounded to nearest on store, exact on load): halves the bytes the decode step is bound
- * by; an extension outside the reference's numerics. Group sizes 1, 2, 4.
+ * by; an extension outside the reference's numerics. Group sizes 1, 2, 4, 8.
  */
 #ifndef NVL_H_
 #define NVL_H_

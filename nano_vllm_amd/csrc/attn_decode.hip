@@ -568,7 +568,10 @@ constexpr int kMWaveLds = kTile * (kMKRow + kMVRow);   // 17,408 B per wave
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
-template <bool FUSED>
+// KV8: the cache holds OCP fp8 e4m3 rows of 128 bytes (opt-in, see decode_stream_fp8_kernel): a tile is loaded as
+// 8 rows x 16 elements per wave instruction and converted (exactly) to bf16 on its way into the wave's LDS tile; the
+// new token's k / v are quantised before they enter this step's softmax. Everything after the LDS write is unchanged.
+template <bool FUSED, bool KV8>
 __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
     int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
@@ -649,7 +652,23 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
           const u32x4_t vnew = *reinterpret_cast<const u32x4_t*>(row + (hq + hkv + h) * 128 + sub * 8);
           knew = norm_rope_head_regs(knew, fa.k_norm_w != nullptr, wk, fa.eps, rr, sub);
           const int tl = len - 1;
-          if (rq == 0) {                                           // one 256-byte row each, for later steps
+          if constexpr (KV8) {
+            // quantise, store the 8 fp8 bytes, and continue with the DEQUANTISED values (what later steps will read)
+            const u32x2_t kq = bf16x8_to_fp8x8(knew), vq = bf16x8_to_fp8x8(vnew);
+            float kf[8], vf[8];
+            unpack_fp8x4(kq[0], kf);
+            unpack_fp8x4(kq[1], kf + 4);
+            unpack_fp8x4(vq[0], vf);
+            unpack_fp8x4(vq[1], vf + 4);
+            knew = pack8(kf);
+            if (rq == 0) {                                         // one 128-byte row each, for later steps
+              const int blk = block_tables[(int64_t)b * bt_stride + tl / block_size];
+              const int64_t dst = (((int64_t)blk * hkv + h) * block_size + (tl % block_size)) * 128 + sub * 8;
+              *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned char*>(kc) + dst) = kq;
+              *reinterpret_cast<u32x2_t*>(reinterpret_cast<unsigned char*>(vc) + dst) = vq;
+              *reinterpret_cast<u32x4_t*>(v_lds + sub * 16) = pack8(vf);               // v row for the O init
+            }
+          } else if (rq == 0) {                                    // one 256-byte row each, for later steps
             const int blk = block_tables[(int64_t)b * bt_stride + tl / block_size];
             const int64_t dst = (((int64_t)blk * hkv + h) * block_size + (tl % block_size)) * 128 + sub * 8;
             *reinterpret_cast<u32x4_t*>(kc + dst) = knew;
@@ -691,23 +710,56 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     for (int ti = t0; ti < t0 + run; ++ti) {
       const int t = ti * kTile;
       const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
-      const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
-      const bf16_t* kp = kc + base;
-      const bf16_t* vp = vc + base;
-      u32x4_t kd[kLoads], vd[kLoads];
+      if constexpr (KV8) {
+        const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
+        const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
+        const unsigned char* vp = reinterpret_cast<const unsigned char*>(vc) + base;
+        u32x4_t kd[kLoads8], vd[kLoads8];
 #pragma unroll
-      for (int i = 0; i < kLoads; ++i) kd[i] = load16_nt(kp + i * 4 * 128);
+        for (int i = 0; i < kLoads8; ++i)
+          kd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kp + i * 8 * 128));
 #pragma unroll
-      for (int i = 0; i < kLoads; ++i) vd[i] = load16_nt(vp + i * 4 * 128);
-      __builtin_amdgcn_sched_barrier(0);  // all 16 loads in flight before the first use
-      // registers -> this wave's LDS tile: row i*4 + rq; K in swizzled 16-byte slots, V row-major (padded)
+        for (int i = 0; i < kLoads8; ++i)
+          vd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vp + i * 8 * 128));
+        __builtin_amdgcn_sched_barrier(0);  // all 8 loads in flight before the first use
+        // lane holds elements 16 (lane & 7) .. of row 8 i + (lane >> 3): bf16 16-byte chunks c0, c0 + 1 of that row
+        const int r8 = lane >> 3, c0 = (lane & 7) * 2;
 #pragma unroll
-      for (int i = 0; i < kLoads; ++i) {
-        const int rowi = i * 4 + rq;
-        *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((sub ^ (rowi & 15)) << 4)) = kd[i];
+        for (int i = 0; i < kLoads8; ++i) {
+          const int rowi = i * 8 + r8;
+          u32x4_t lo16, hi16;
+          fp8x16_to_bf16(kd[i], &lo16, &hi16);
+          *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((c0 ^ (rowi & 15)) << 4)) = lo16;
+          *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + (((c0 + 1) ^ (rowi & 15)) << 4)) = hi16;
+        }
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i) {
+          const int rowi = i * 8 + r8;
+          u32x4_t lo16, hi16;
+          fp8x16_to_bf16(vd[i], &lo16, &hi16);
+          *reinterpret_cast<u32x4_t*>(v_lds + rowi * kMVRow + c0 * 16) = lo16;
+          *reinterpret_cast<u32x4_t*>(v_lds + rowi * kMVRow + (c0 + 1) * 16) = hi16;
+        }
+      } else {
+        const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
+        const bf16_t* kp = kc + base;
+        const bf16_t* vp = vc + base;
+        u32x4_t kd[kLoads], vd[kLoads];
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) kd[i] = load16_nt(kp + i * 4 * 128);
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) vd[i] = load16_nt(vp + i * 4 * 128);
+        __builtin_amdgcn_sched_barrier(0);  // all 16 loads in flight before the first use
+        // registers -> this wave's LDS tile: row i*4 + rq; K in swizzled 16-byte slots, V row-major (padded)
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+          const int rowi = i * 4 + rq;
+          *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((sub ^ (rowi & 15)) << 4)) = kd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i)
+          *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
       }
-#pragma unroll
-      for (int i = 0; i < kLoads; ++i) *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
 
       // ---- S^T: two 16-token halves x four 32-dim chunks ------------------------------------------------
       f32x4_t sacc[2];
@@ -834,7 +886,7 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
 
 inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 2; }
 
-template <bool FUSED>
+template <bool FUSED, bool KV8>
 int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                         void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
                         void* workspace, hipStream_t s, const FusedArgs& fa) {
@@ -848,7 +900,7 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_kernel<FUSED>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_kernel<FUSED, KV8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the G = 8 kernel");
       return NVL_ELAUNCH;
@@ -862,7 +914,7 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
   const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
   if (grid > max_wg) grid = max_wg;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((decode_mfma8_kernel<FUSED>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
+  hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
                      (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
                      block_size, slots, scale * 1.4426950408889634f, fa);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
@@ -977,8 +1029,15 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
       NVL_DECODE8_CASE(1)
       NVL_DECODE8_CASE(2)
       NVL_DECODE8_CASE(4)
+      case 8:   // matrix-core variant: fp8 tiles are converted to bf16 on their way into LDS
+        return fa ? launch_decode_mfma8<true, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
+                                                    batch, num_kv_heads, block_size, max_context, softmax_scale,
+                                                    workspace, s, *fa)
+                  : launch_decode_mfma8<false, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
+                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,
+                                                     workspace, s, none);
       default:
-        nvl_set_error("%s: fp8 KV cache supports group sizes Hq/Hkv in {1, 2, 4} (got %d)", who, G);
+        nvl_set_error("%s: unsupported group size Hq/Hkv=%d (supported 1,2,4,8)", who, G);
         return NVL_EUNSUPPORTED;
     }
 #undef NVL_DECODE8_CASE
@@ -997,10 +1056,12 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
     NVL_DECODE_CASE(4)
     case 8:   // matrix-core variant (the packed-dot kernel is VALU-bound at 8 FLOP/B); NVL_DECODE_G8_VALU=1 keeps it
       if (!use_valu_g8())
-        return fa ? launch_decode_mfma8<true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
-                                              num_kv_heads, block_size, max_context, softmax_scale, workspace, s, *fa)
-                  : launch_decode_mfma8<false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
-                                               num_kv_heads, block_size, max_context, softmax_scale, workspace, s, none);
+        return fa ? launch_decode_mfma8<true, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
+                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,
+                                                     workspace, s, *fa)
+                  : launch_decode_mfma8<false, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
+                                                      batch, num_kv_heads, block_size, max_context, softmax_scale,
+                                                      workspace, s, none);
       return fa ? launch_decode_stream<8, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
                                                 num_kv_heads, block_size, max_context, softmax_scale, workspace, s, *fa)
                 : launch_decode_stream<8, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,

@@ -424,8 +424,6 @@ class ModelRunner:
         stats = torch.cuda.memory_stats()
         peak, current = stats["allocated_bytes.all.peak"], stats["allocated_bytes.all.current"]
         fp8 = cfg.kv_cache_dtype == "fp8"
-        if fp8:
-            assert geo["heads"] // geo["kv_heads"] in (1, 2, 4), "fp8 KV cache: group sizes 1, 2, 4 (see include/nvl.h)"
         block_bytes = 2 * geo["layers"] * self.block_size * geo["kv_heads"] * geo["head_dim"] * (1 if fp8 else 2)
         if cfg.num_kvcache_blocks <= 0:
             assert not (self.world_size > 1 and os.environ.get("NVL_TP_SHARE_GPU") == "1"), \

@@ -47,9 +47,9 @@ def test_host_side_argument_validation_without_gpu():
     assert rc == -1 and b"not a multiple" in lib.nvl_last_error()
     rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8, 4096, 0.1, 16, 1 << 30, 7, None)
     assert rc == -1 and b"kv_dtype" in lib.nvl_last_error()
-    # the fp8 KV cache covers group sizes 1, 2, 4 (the G = 8 matrix-core kernel reads bf16): refused, not emulated
-    rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 64, 8, 256, 8, 4096, 0.1, 16, 1 << 30, 1, None)
-    assert rc == -3 and b"group sizes" in lib.nvl_last_error()
+    # group sizes outside 1, 2, 4, 8 are refused (either cache dtype), not emulated
+    rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 48, 16, 256, 16, 4096, 0.1, 16, 1 << 30, 1, None)
+    assert rc == -3 and b"group size" in lib.nvl_last_error()
     # fused decode entry: rope table is mandatory; q/k norm weights come as a pair
     rc = lib.nvl_paged_attn_decode_fused(16, 4096, None, None, 1e-6, None, 0, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
                                          4096, 0.1, 16, 1 << 30, 0, None)

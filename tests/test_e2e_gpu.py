@@ -431,11 +431,16 @@ def test_lookahead_and_microbatch_modes_reproduce_the_serial_engine(tiny_ckpt, m
     assert run(0.0) == run(0.0, NVL_MICROBATCHES="2")
 
 
-def test_fp8_kv_cache_engine_runs_and_stays_close_to_the_bf16_engine(tiny_ckpt):
-    """kv_cache_dtype="fp8" end to end (prefill store, fused decode, chunked prefill reading the fp8 cache, hipGraph):
-    an extension outside the reference's numerics, so the bar is agreement with OUR bf16 engine on the first tokens
-    (one or two forward passes deep, before quantisation noise can flip a near-tie and the histories diverge)."""
+@pytest.mark.parametrize("name", ["qwen3-tiny", "qwen3-tiny-untied", "qwen3-tiny-g8"])
+def test_fp8_kv_cache_engine_runs_and_stays_close_to_the_bf16_engine(name):
+    """kv_cache_dtype="fp8" end to end (prefill store, fused decode, chunked prefill reading the fp8 cache, hipGraph),
+    at group sizes 2, 4 (streaming kernel) and 8 (matrix-core kernel): an extension outside the reference's numerics,
+    so the bar is agreement with OUR bf16 engine on the first tokens (one or two forward passes deep, before
+    quantisation noise can flip a near-tie and the histories diverge)."""
     from nano_vllm_amd import LLM, SamplingParams
+    from nano_vllm_amd.weights import write_synthetic_checkpoint
+    tiny_ckpt = tempfile.mkdtemp(prefix=name.replace("-", "_") + "_fp8_")
+    write_synthetic_checkpoint(tiny_ckpt, name, seed=2, vocab_size=512, max_position_embeddings=2048)
     prompts = _prompts(8, 5, 700, 512, seed=43)
     sp = SamplingParams(temperature=0.0, max_tokens=16, ignore_eos=True)
 

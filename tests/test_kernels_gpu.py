@@ -548,7 +548,7 @@ def test_fp8_kv_store_matches_torch_cast_bit_for_bit(ops, n, h, hkv):
     assert torch.equal(got, ref_k.to(torch.float8_e4m3fn).view(torch.uint8))
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (16, 2), (64, 8)])
 @pytest.mark.parametrize("lens", [[1], [255, 256, 257, 33], [1, 100, 1023, 1024, 1025, 2048, 17, 0, 640], [4096, 3, 0, 700]])
 def test_fp8_kv_decode_fused_vs_oracle_on_the_dequantised_cache(ops, hq, hkv, lens):
     """nvl_paged_attn_decode_fused with an fp8 cache: (1) the new token's K/V rows land in the cache as the fp8 cast
