@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--pool-blocks", type=int, default=9380, help="KV pool the schedule is recorded with")
     ap.add_argument("--fused", action="store_true", help="time nvl_paged_attn_decode_fused (norm+rope+store inside)")
     ap.add_argument("--layer-major", action="store_true", help="cache laid out [L, 2, blocks, ...] instead of [2, L, blocks, ...]")
+    ap.add_argument("--fp8", action="store_true", help="OCP fp8 e4m3 KV cache (opt-in extension; 128-byte rows)")
     ap.add_argument("--cache-blocks", type=int, default=0,
                     help="allocate the cache with this many blocks per layer (like the engine's pool) instead of only the used ones")
     args = ap.parse_args()
@@ -135,9 +136,14 @@ def main():
         kv = torch.empty(2, args.layers, nblk, args.hkv, 256, 128, dtype=torch.bfloat16, device=dev)
     for layer in range(args.layers):               # random (not zero) data: zero-filled inputs clock higher
         kv[:, layer, :used].normal_()
+    if args.fp8:
+        kv8 = torch.empty(kv.shape, dtype=torch.float8_e4m3fn, device=dev)
+        for layer in range(args.layers):
+            kv8[:, layer, :used] = kv[:, layer, :used].to(torch.float8_e4m3fn)
+        kv = kv8
     ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(512, args.hq, 4096), dtype=torch.uint8, device=dev)
     r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps, fused=args.fused)
-    r.update(stats, kernel=f"decode_stream_kernel<{args.hq // args.hkv}, {str(args.fused).lower()}>", kv_blocks_used=nblk, samples=len(samples),
+    r.update(stats, kernel=f"decode<G={args.hq // args.hkv}, fused={str(args.fused).lower()}, kv={'fp8' if args.fp8 else 'bf16'}>", kv_blocks_used=nblk, samples=len(samples),
              frac_of_8TBps=r["achieved_GBps"] / 8000.0)
     print(json.dumps(r), flush=True)
 

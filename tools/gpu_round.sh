@@ -75,6 +75,12 @@ prefillw)
   NVL_PREFILL_WAVES=8 timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -k "prefill" 2>&1 | tail -3;;
 replay)
   timeout 600 python tools/attn_replay.py --fused > $OUT/replay.json 2> $OUT/replay.err; cat $OUT/replay.json;;
+fp8g8)
+  timeout 900 python -m pytest tests -m gpu -q -rf -k "fp8" > $OUT/pytest_fp8.log 2>&1; echo "fp8 tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|fp8 KV vs" $OUT/pytest_fp8.log | tail -12
+  for f in "" "--fp8"; do
+    timeout 600 python tools/attn_replay.py --fused --hq 8 --hkv 1 --layers 64 --every 16 $f > $OUT/replay_g8$f.json 2> $OUT/replay_g8$f.err; cat $OUT/replay_g8$f.json
+    timeout 600 python tools/attn_replay.py --fused --hq 16 --hkv 2 --layers 64 --every 16 $f > $OUT/replay_g8x2$f.json 2> $OUT/replay_g8x2$f.err; cat $OUT/replay_g8x2$f.json
+  done;;
 *) echo "unknown step $w";;
 esac
 done
