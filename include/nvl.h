@@ -109,6 +109,22 @@ int nvl_linear_decode_splits(int64_t m, int n, int k, int mode);
 int nvl_linear_decode(const void* x, const void* weight, void* out,
                       int64_t m, int n, int k, int mode, void* stream);
 
+/* Decode-time linear layers on DEEP reductions (Qwen3-8B / 32B projections, full width and
+ * per-rank TP shapes): the same contract as nvl_linear_decode (modes 0 / 1 / 2, reference
+ * layers/linear.py:54-156 + layers/activation.py:8-11), a different decomposition: a workgroup
+ * covers 128-256 output columns, stages the x tile of a 128-wide k step once in LDS for its 8
+ * waves and streams its weight rows HBM -> VGPR; small-N shapes are additionally split over K
+ * across workgroups.
+ *   nvl_linear_wide_plan: 1 if the shape is covered (0 = not: use another path). *splits = K
+ *     splits of the chosen plan (mode 2: `out` holds that many [m, n] fp32 slabs, consumed by
+ *     nvl_add_rmsnorm_splitk); *workspace_bytes = scratch the call needs for modes 0 / 1 when
+ *     the plan splits K (0 otherwise).
+ *   nvl_linear_wide: NVL_EUNSUPPORTED when the plan query says 0. k % 128 == 0, n % 16 == 0
+ *     (mode 1: n % 32 == 0). */
+int nvl_linear_wide_plan(int64_t m, int n, int k, int mode, int* splits, size_t* workspace_bytes);
+int nvl_linear_wide(const void* x, const void* weight, void* out, int64_t m, int n, int k, int mode,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* Fused split-K reduction + residual add + RMSNorm: replaces
  * RMSNorm.add_rms_forward (layers/layernorm.py:28-40) when its input is the
  * fp32 partials of nvl_linear_decode mode 2:

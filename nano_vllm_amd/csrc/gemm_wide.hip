@@ -1,0 +1,472 @@
+// Wide-tile streaming linear layers for gfx950: out[M, N] = x[M, K] . W[N, K]^T for decode steps (M <= a few hundred
+// rows) on DEEP reductions — the Qwen3-8B / 32B projections (K = 4096 ... 25,600), full width and per-rank TP shapes.
+// Replaces F.linear as called from LinearBase.forward (nano-vllm layers/linear.py:54-156) on those shapes, with the
+// reference's activation glue (SiluAndMul, layers/activation.py:8-11) and the split-K slab hand-off to
+// nvl_add_rmsnorm_splitk in the epilogues, like nvl_linear_decode does for K <= 1024.
+//
+// Why a second decomposition. gemm_decode.hip gives a workgroup 16-32 output columns and splits K over its 8
+// waves: every workgroup ingests all M rows of x for those few columns, which is fine at K = 1024 (268 KB) and
+// hopeless at K = 4096+ (x traffic L2 -> CU = M / 32 = 4.5x the weight bytes at 144 rows;
+// profiles/r02_gemm_deep_*.json: 1.6-2.2 TB/s, below hipBLASLt). Here the ratio is M / (columns per workgroup):
+//   * workgroup = NW = 3 or 4 CONSUMER waves + 1 LOADER wave, one workgroup per CU. Consumer wave w owns NT (1 or 2)
+//     sixteen-column MFMA tiles x ALL row tiles of its row group (a workgroup covers 48 ... 128 output columns, no
+//     cross-wave reduction). Few fat waves instead of 8 thin ones: every x fragment read from LDS feeds NT MFMAs
+//     and only NW waves read it (8 waves with NT = 1 are LDS-bound at 144 rows: 288 ds_read_b128 per step).
+//   * K advances in 128-wide steps. The loader wave stages the x tile of step s + 2 ([rows, 128] bf16, 36 KiB at 144
+//     rows) with LDS-DMA (row-contiguous global_load_lds_dwordx4 from L2 into 16-byte XOR-swizzled slots =>
+//     conflict-free ds_read_b128 B fragments) while the consumers work on step s; three LDS stages, one barrier
+//     per step.
+//   * Consumers stream their W fragments HBM -> VGPR with non-temporal loads through a RING-deep register ring
+//     (the loads of step s + RING - 1 are issued at the start of step s): (RING - 1) x NT x 4 KiB in flight per
+//     wave. The x loads live in a DIFFERENT wave because a wave's loads retire in order: in the first version every
+//     wave loaded x chunks too, and waiting for the x of step s + 1 (an L2 hit) also waited for every older weight
+//     load, i.e. the ring was drained to its newest set at every step (~18 GB/s per CU whatever RING was).
+//   * The K loop's body is RING steps of straight-line code with UNCONDITIONAL (index-clamped) prefetches and
+//     unconditional uses, so both edges into the loop header carry the same outstanding-load pattern and hipcc's
+//     s_waitcnt stays counted; a load whose only use sits under a branch is sunk into it and becomes synchronous
+//     (both seen in the .s of earlier versions). The steps % RING tail runs after the loop on the ring's loaded sets.
+//   * Small-N shapes (qkv / o / down, and everything per-rank under TP) do not have ~256 column tiles: K is split
+//     over workgroups as well (grid.y) and the partial tiles leave as fp32 slabs [split][M][N]. For o_proj / down_proj
+//     the consumer (nvl_add_rmsnorm_splitk) sums the slabs in its prologue ("reduce at the launch boundary"); for
+//     bf16 / SiLU outputs a small reduce kernel follows (slab_reduce_kernel).
+//   * v_mfma_f32_16x16x32_bf16, A = W fragment, B = x fragment: lane (l15 = lane & 15, lq = lane >> 4) ends up with
+//     out[row = 16 mt + l15][col = tile + 4 lq .. + 3] => 8-byte bf16 / 16-byte fp32 stores.
+//   * SiLU: a wave's two tiles are a gate tile and the matching up tile, paired in registers.
+// Rounding points are the reference's: the GEMM output is rounded to bf16 before the activation.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kBK = 128;                 // k per step
+constexpr int kKB = kBK / 32;            // 32-wide MFMA k blocks per step
+enum { EPI_BF16 = 0, EPI_SILU = 1, EPI_PARTIAL = 2 };
+
+__device__ __forceinline__ float silu_f32(float g) { return g / (1.f + __expf(-g)); }
+
+template <int MT, int NT, int NW, int EPI, int RING>
+__global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
+                                                                     const bf16_t* __restrict__ w,
+                                                                     void* __restrict__ out, int M, int N, int K,
+                                                                     int steps) {
+  constexpr int kRows = MT * 16;
+  constexpr int kStage = kRows * 256;                             // bytes per LDS stage
+  static_assert(EPI != EPI_SILU || NT == 2, "SiLU: a wave holds a gate tile and its up tile");
+  constexpr int GT = EPI == EPI_SILU ? 1 : NT;                    // output tiles per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int m_base = blockIdx.z * kRows;
+  const int out_cols = EPI == EPI_SILU ? N / 2 : N;
+  const int64_t k0 = (int64_t)blockIdx.y * steps * kBK;
+  const int last = steps - 1;
+  // Workgroups walk their K range from different starting steps (wrapping around): rows of W are K * 2 bytes apart, so
+  // workgroups marching in lock-step would all touch the same offset inside an 8-16 KiB stride at the same time
+  // (the same few HBM channels).
+  const int rot = (int)((blockIdx.x + 3u * blockIdx.y) % (unsigned)steps);
+  auto kstep = [&](int s) {                                       // logical step (prefetches past the end clamp) -> k step
+    s = (s < last ? s : last) + rot;
+    return s >= steps ? s - steps : s;
+  };
+
+  if (wave == NW) {
+    // ---- loader wave: x tile of step s + 2 -> LDS stage (s + 2) % 3 while the consumers work on step s -----------
+    // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land at M0 + 16 lane, no staging registers), two steps in
+    // flight: staging a step is one L2 round trip long, and with a single step in flight that round trip was the
+    // step time of the whole workgroup (first loader version: 1.7 us per step at 16 rows). Instruction i covers
+    // LDS chunks 64 i .. 64 i + 63 = rows 4 i + lq, slots l15; the XOR swizzle is applied on the SOURCE side (slot
+    // l15 of row r holds chunk l15 ^ (r & 15)), so an instruction still reads 4 rows x 256 contiguous bytes.
+    // The loads are inline asm (hipcc neither counts them nor keeps M0), so this wave's waits are explicit.
+    constexpr int kLC = MT * 4;
+    static_assert(kLC < 64, "vmcnt is a 6-bit counter");
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const bf16_t* xb = x + k0;
+    int x_src[kLC];                                               // element offsets (M * K < 2^31)
+#pragma unroll
+    for (int i = 0; i < kLC; ++i) {
+      const int row = 4 * i + lq;
+      int grow = m_base + row;
+      grow = grow < M ? grow : M - 1;                             // padding rows read a valid row (never stored)
+      x_src[i] = grow * K + ((l15 ^ (row & 15)) << 3);
+    }
+    auto issue = [&](int s) {
+      const unsigned dst = lds0 + (unsigned)(s % 3) * kStage;
+      const bf16_t* src = xb + kstep(s) * kBK;
+#pragma unroll
+      for (int i = 0; i < kLC; ++i) {
+        unsigned keep;
+        const unsigned d = __builtin_amdgcn_readfirstlane(dst + i * 1024);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src + x_src[i]), "s"(d)
+                     : "memory");
+      }
+    };
+    issue(0);
+    if (steps > 1) {
+      issue(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC) : "memory");   // step 0 has landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < steps; ++s) {
+      // stage (s + 2) % 3 was last read during step s - 1: free since the previous barrier
+      if (s + 2 <= last) {
+        issue(s + 2);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC) : "memory"); // step s + 1 has landed
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
+
+  // ---- consumer waves ----------------------------------------------------------------------------------------------
+  // first output column of this wave's tiles, and the W rows feeding them (SiLU: tile 0 = gate, tile 1 = up)
+  const int n0 = (blockIdx.x * NW + wave) * (GT * 16);
+  const bf16_t* wrow[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    int row = n0 + (nt % GT) * 16 + l15;
+    row = row < out_cols ? row : out_cols - 1;                    // ragged last workgroup: any valid row, masked below
+    if (EPI == EPI_SILU && nt >= GT) row += out_cols;
+    wrow[nt] = w + (int64_t)row * K + k0 + lq * 8;
+  }
+  int frag_off[kKB];                                              // B fragment of k block kb: row l15 of a row tile
+#pragma unroll
+  for (int kb = 0; kb < kKB; ++kb) frag_off[kb] = l15 * 256 + (((kb * 4 + lq) ^ l15) << 4);
+
+  f32x4_t acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  u32x4_t wf[RING][NT][kKB];
+  auto wload = [&](u32x4_t (*dst)[kKB], int s) {
+    s = kstep(s);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int kb = 0; kb < kKB; ++kb)
+        dst[nt][kb] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[nt] + s * kBK + kb * 32));
+  };
+
+  // one k step: the MFMAs of every row tile against the weight set `wfs`, x fragments from LDS stage `xs`.
+  // Row tiles go through the matrix pipe in groups of PT (2 independent accumulation chains per group either way);
+  // the fragments of group g + 1 are read from LDS under the MFMAs of group g (pinned: hipcc otherwise re-serialises
+  // read -> wait -> 2 MFMAs through one register quad).
+  auto compute = [&](const unsigned char* xs, const u32x4_t (*wfs)[kKB]) {
+    constexpr int PT = NT == 1 ? 2 : 1;
+    constexpr int NG = (MT + PT - 1) / PT;
+    u32x4_t f[2][PT][kKB];
+    auto fread = [&](int g, u32x4_t (*dst)[kKB]) {
+#pragma unroll
+      for (int t = 0; t < PT; ++t)
+        if (g * PT + t < MT) {
+#pragma unroll
+          for (int kb = 0; kb < kKB; ++kb)
+            dst[t][kb] = *reinterpret_cast<const u32x4_t*>(xs + (g * PT + t) * 16 * 256 + frag_off[kb]);
+        }
+    };
+    fread(0, f[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      if (g + 1 < NG) fread(g + 1, f[(g + 1) & 1]);
+#pragma unroll
+      for (int kb = 0; kb < kKB; ++kb)
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+          if (g * PT + t < MT) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[g * PT + t][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                  __builtin_bit_cast(bf16x8_t, wfs[nt][kb]), __builtin_bit_cast(bf16x8_t, f[g & 1][t][kb]),
+                  acc[g * PT + t][nt], 0, 0, 0);
+          }
+      if (g + 1 < NG) {
+#pragma unroll
+        for (int j = 0; j < PT * kKB; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read ...
+          __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // ... per NT MFMAs
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // Pipeline invariant at the top of step s (ring slot i = s mod RING): LDS stage s % 3 holds x of step s (loader),
+  // wf[i] .. wf[i + RING - 2] hold (or have in flight) the weights of steps s .. s + RING - 2.
+#pragma unroll
+  for (int r = 0; r < RING - 1; ++r) wload(wf[r], r);
+  __syncthreads();                                                // stage 0 is staged
+  const int nblk = steps / RING;
+  for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+    for (int i = 0; i < RING; ++i) {
+      const int s = blk * RING + i;
+      wload(wf[(i + RING - 1) % RING], s + RING - 1);             // the weights RING - 1 steps ahead
+      __builtin_amdgcn_sched_barrier(0);
+      compute(smem + (s % 3) * kStage, wf[i]);
+      __syncthreads();                                            // stage (s + 1) % 3 is staged, stage s % 3 is free
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i) {
+    const int s = nblk * RING + i;
+    if (s < steps) {
+      compute(smem + (s % 3) * kStage, wf[i]);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m_base + mt * 16 + l15;
+    if (m >= M) continue;
+#pragma unroll
+    for (int gt = 0; gt < GT; ++gt) {
+      const int n = n0 + gt * 16;
+      if (n >= out_cols) continue;
+      if constexpr (EPI == EPI_SILU) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = silu_f32(round_bf16(acc[mt][0][r])) * round_bf16(acc[mt][1][r]);
+        u32x2_t ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        *reinterpret_cast<u32x2_t*>((bf16_t*)out + (int64_t)m * out_cols + n + lq * 4) = ov;
+      } else if constexpr (EPI == EPI_BF16) {
+        u32x2_t o = {pack_bf16x2(acc[mt][gt][0], acc[mt][gt][1]), pack_bf16x2(acc[mt][gt][2], acc[mt][gt][3])};
+        *reinterpret_cast<u32x2_t*>((bf16_t*)out + (int64_t)m * N + n + lq * 4) = o;
+      } else {
+        *reinterpret_cast<f32x4_t*>((float*)out + ((int64_t)blockIdx.y * M + m) * N + n + lq * 4) = acc[mt][gt];
+      }
+    }
+  }
+}
+
+// out = epilogue(sum_s part[s]) for bf16 / SiLU outputs whose GEMM was split over K: 4 output columns per thread,
+// every slab piece requested before the first add (one memory round trip); slabs are summed in split order.
+template <int EPI>
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ part, int splits,
+                                                           int64_t split_stride, bf16_t* __restrict__ out, int M,
+                                                           int N) {
+  const int out_cols = EPI == EPI_SILU ? N / 2 : N;
+  const int qpr = out_cols >> 2;                                  // quads per row
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (int64_t)M * qpr) return;
+  const int row = (int)(q / qpr), c = (int)(q - (int64_t)row * qpr) * 4;
+  const float* p = part + (int64_t)row * N + c;
+  f32x4_t a = *reinterpret_cast<const f32x4_t*>(p);
+  f32x4_t b = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (EPI == EPI_SILU) b = *reinterpret_cast<const f32x4_t*>(p + out_cols);
+  for (int s = 1; s < splits; ++s) {
+    a += *reinterpret_cast<const f32x4_t*>(p + s * split_stride);
+    if constexpr (EPI == EPI_SILU) b += *reinterpret_cast<const f32x4_t*>(p + s * split_stride + out_cols);
+  }
+  float o[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) o[r] = EPI == EPI_SILU ? silu_f32(round_bf16(a[r])) * round_bf16(b[r]) : a[r];
+  u32x2_t ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+  *reinterpret_cast<u32x2_t*>(out + (int64_t)row * out_cols + c) = ov;
+}
+
+// ---- host: plan ---------------------------------------------------------------------------------------------------
+struct WidePlan {
+  int mt, nt, nw, mgroups, tiles, split, steps;   // tiles = workgroups along N; steps = 128-wide k steps per workgroup
+};
+
+// Weight ring depth. 5 waves (NW = 4) share 4 SIMDs, so those kernels live in 256 registers: one set less at 7+ row
+// tiles x 2 column tiles.
+constexpr int ring_of(int nt, int nw, int mt) {
+  if (nw == 3) return nt == 1 ? 8 : 6;          // 4 waves, one per SIMD: 512 registers per wave
+  return nt == 1 ? 6 : (mt >= 7 ? 3 : 4);
+}
+
+int env_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e && *e ? atoi(e) : dflt;
+}
+
+// Row-tile counts that are instantiated (a batch is rounded up to the next one; the x rows past M are clamped reads)
+int round_mt(int mtiles, int nt) {
+  static const int kMT[] = {1, 2, 3, 5, 7, 9};
+  for (int c : kMT)
+    if (c >= mtiles) return c;
+  return 0;
+}
+
+// Model of one launch (us) for a candidate decomposition. A CU streams ~20 GB/s of weights however much it keeps in
+// flight, so time ~ (rounds of 256 workgroups) x (steps per workgroup) x (time of a step on one CU), where a step is
+// bound by its weight bytes at that rate, by its MFMAs (one wave per SIMD) or by staging x (L2 -> LDS); plus the
+// pipeline fill per workgroup, the launch, and the slab traffic when K is split.
+double wide_cost(int64_t m, int n, int k, int mode, const WidePlan& p) {
+  const int wgs = p.tiles * p.split * p.mgroups;
+  const double rounds = (double)((wgs + 255) / 256);
+  const double wbytes_step = (double)p.nw * p.nt * 16 * 256.0;
+  const double t_w = wbytes_step / 20.0e3;                                        // us at 20 GB/s per CU
+  const double t_mfma = (double)p.mt * p.nt * kKB * 16.0 / 2400.0;               // 16 clk per MFMA at 2.4 GHz
+  const double t_x = (double)p.mt * 16 * 256.0 / 100.0e3 + 0.15;                 // ~100 GB/s L2 -> LDS + barrier
+  double t_step = t_w;
+  if (t_mfma > t_step) t_step = t_mfma;
+  if (t_x > t_step) t_step = t_x;
+  // the whole chip cannot exceed ~5 TB/s either
+  const double active = wgs < 256 ? wgs : 256;
+  const double chip = active * wbytes_step / 5.0e6;
+  if (chip > t_step) t_step = chip;
+  double t = rounds * (p.steps * t_step + 2.0) + 2.5;
+  if (p.split > 1 || mode == EPI_PARTIAL) {
+    const double slab = (double)p.split * m * n * 4.0;
+    t += slab / 4.0e6;                                                            // written here ...
+    if (mode != EPI_PARTIAL) t += slab / 4.0e6 + 3.5;                             // ... re-read by the reduce kernel
+    else t += (p.split - 1) * (double)m * n * 4.0 / 6.0e6;                        // ... or by the consumer's prologue
+  }
+  return t;
+}
+
+bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
+  if (m < 1 || m > 1024 || n < 16 || k < kBK || k % kBK) return false;
+  if (mode == EPI_SILU ? n % 32 : n % 16) return false;
+  const int out_cols = mode == EPI_SILU ? n / 2 : n;
+  const int mtiles = (int)((m + 15) / 16);
+  const int ksteps = k / kBK;
+  const int force_nt = env_int("NVL_WIDE_NT", 0), force_nw = env_int("NVL_WIDE_NW", 0);
+  const int force_split = env_int("NVL_WIDE_SPLIT", 0);
+  double best_t = 1e30;
+  for (int nt : {2, 1}) {
+    if (force_nt && nt != force_nt) continue;
+    if (mode == EPI_SILU && nt == 1) continue;
+    for (int nw : {4, 3}) {
+      if (force_nw && nw != force_nw) continue;
+      WidePlan p;
+      p.nt = nt;
+      p.nw = nw;
+      // <= 9 row tiles per row group (accumulators + weight ring + fragments in the register file); more rows = more
+      // row groups (grid.z), whose workgroups run side by side and share the weight stream through L2 / MALL
+      const int mt_max = 9;
+      p.mgroups = (mtiles + mt_max - 1) / mt_max;
+      p.mt = round_mt((mtiles + p.mgroups - 1) / p.mgroups, nt);
+      if (!p.mt) continue;
+      const int cols = nw * (mode == EPI_SILU ? 1 : nt) * 16;
+      p.tiles = (out_cols + cols - 1) / cols;
+      for (int split = 1; split <= 32; ++split) {
+        if (ksteps % split) continue;
+        if (force_split && split != force_split) continue;
+        if (split > 1 && ksteps / split < 2) break;
+        p.split = split;
+        p.steps = ksteps / split;
+        const double t = wide_cost(m, n, k, mode, p);
+        if (t < best_t) { best_t = t; *best = p; }
+      }
+    }
+  }
+  if (best_t < 1e30 && env_int("NVL_WIDE_DEBUG", 0))
+    fprintf(stderr, "nvl_linear_wide plan m=%lld n=%d k=%d mode=%d: nt=%d nw=%d mt=%d groups=%d tiles=%d split=%d steps=%d -> %d wgs, model %.1f us\n",
+            (long long)m, n, k, mode, best->nt, best->nw, best->mt, best->mgroups, best->tiles, best->split, best->steps,
+            best->tiles * best->split * best->mgroups, best_t);
+  return best_t < 1e30;
+}
+
+template <int MT, int NT, int NW, int EPI>
+int launch_wide(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
+  constexpr int RING = ring_of(NT, NW, MT);
+  const size_t lds = (size_t)3 * MT * 16 * 256;
+  static bool attr_done[NVL_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[nvl_device_slot()];
+  if (!attr_set && lds > 64 * 1024) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wide_kernel<MT, NT, NW, EPI, RING>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      nvl_set_error("nvl_linear_wide: cannot reserve %zu B of LDS", lds);
+      return NVL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING>), dim3(p.tiles, p.split, p.mgroups), dim3((NW + 1) * 64), lds,
+                     s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps);
+  return NVL_OK;
+}
+
+template <int NT, int NW, int EPI>
+int dispatch_mt(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
+  switch (p.mt) {
+    case 1: return launch_wide<1, NT, NW, EPI>(p, x, w, out, m, n, k, s);
+    case 2: return launch_wide<2, NT, NW, EPI>(p, x, w, out, m, n, k, s);
+    case 3: return launch_wide<3, NT, NW, EPI>(p, x, w, out, m, n, k, s);
+    case 5: return launch_wide<5, NT, NW, EPI>(p, x, w, out, m, n, k, s);
+    case 7: return launch_wide<7, NT, NW, EPI>(p, x, w, out, m, n, k, s);
+    case 9: return launch_wide<9, NT, NW, EPI>(p, x, w, out, m, n, k, s);
+  }
+  nvl_set_error("nvl_linear_wide: internal plan error (mt=%d nt=%d nw=%d)", p.mt, p.nt, p.nw);
+  return NVL_EINVAL;
+}
+
+template <int EPI>
+int dispatch_wide(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
+#define NVL_W_CASE(NT_, NW_) \
+  if (p.nt == NT_ && p.nw == NW_) return dispatch_mt<NT_, NW_, EPI>(p, x, w, out, m, n, k, s);
+  if constexpr (EPI != EPI_SILU) { NVL_W_CASE(1, 3) NVL_W_CASE(1, 4) }
+  NVL_W_CASE(2, 3) NVL_W_CASE(2, 4)
+#undef NVL_W_CASE
+  nvl_set_error("nvl_linear_wide: internal plan error (nt=%d nw=%d)", p.nt, p.nw);
+  return NVL_EINVAL;
+}
+
+}  // namespace
+
+extern "C" int nvl_linear_wide_plan(int64_t m, int n, int k, int mode, int* splits, size_t* workspace_bytes) {
+  WidePlan p;
+  if (mode < 0 || mode > 2 || !wide_plan(m, n, k, mode, &p)) return 0;
+  if (splits) *splits = p.split;
+  if (workspace_bytes) *workspace_bytes = mode != EPI_PARTIAL && p.split > 1 ? (size_t)p.split * m * n * sizeof(float) : 0;
+  return 1;
+}
+
+extern "C" int nvl_linear_wide(const void* x, const void* weight, void* out, int64_t m, int n, int k, int mode,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  NVL_REQUIRE(x && weight && out, "nvl_linear_wide: null pointer");
+  NVL_REQUIRE(mode >= 0 && mode <= 2, "nvl_linear_wide: mode=%d (0 bf16, 1 silu*mul, 2 split-K fp32 partials)", mode);
+  NVL_REQUIRE(((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)workspace) % 16 == 0,
+              "nvl_linear_wide: pointers must be 16-byte aligned");
+  WidePlan p;
+  if (!wide_plan(m, n, k, mode, &p)) {
+    nvl_set_error("nvl_linear_wide: shape m=%lld n=%d k=%d mode=%d not covered (query nvl_linear_wide_plan first)",
+                  (long long)m, n, k, mode);
+    return NVL_EUNSUPPORTED;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == EPI_PARTIAL) {
+    const int rc = dispatch_wide<EPI_PARTIAL>(p, x, weight, out, m, n, k, s);
+    return rc != NVL_OK ? rc : nvl_check_launch("nvl_linear_wide");
+  }
+  if (p.split == 1) {
+    const int rc = mode == EPI_SILU ? dispatch_wide<EPI_SILU>(p, x, weight, out, m, n, k, s)
+                                    : dispatch_wide<EPI_BF16>(p, x, weight, out, m, n, k, s);
+    return rc != NVL_OK ? rc : nvl_check_launch("nvl_linear_wide");
+  }
+  const size_t need = (size_t)p.split * m * n * sizeof(float);
+  NVL_REQUIRE(workspace && workspace_bytes >= need, "nvl_linear_wide: workspace %zu B < required %zu B", workspace_bytes,
+              need);
+  // split-K with a bf16 / SiLU output: the GEMM runs as if its columns were independent (a SiLU pair is formed by
+  // the reduce kernel), slabs go to the workspace
+  WidePlan q = p;
+  if (mode == EPI_SILU) {   // plain column tiling over all N = gate | up columns
+    const int cols = q.nw * q.nt * 16;
+    q.tiles = (n + cols - 1) / cols;
+  }
+  int rc = dispatch_wide<EPI_PARTIAL>(q, x, weight, workspace, m, n, k, s);
+  if (rc != NVL_OK) return rc;
+  const int out_cols = mode == EPI_SILU ? n / 2 : n;
+  const int64_t quads = m * (int64_t)(out_cols / 4);
+  const unsigned blocks = (unsigned)((quads + 255) / 256);
+  if (mode == EPI_SILU)
+    hipLaunchKernelGGL(slab_reduce_kernel<EPI_SILU>, dim3(blocks), dim3(256), 0, s, (const float*)workspace, p.split,
+                       (int64_t)m * n, (bf16_t*)out, (int)m, n);
+  else
+    hipLaunchKernelGGL(slab_reduce_kernel<EPI_BF16>, dim3(blocks), dim3(256), 0, s, (const float*)workspace, p.split,
+                       (int64_t)m * n, (bf16_t*)out, (int)m, n);
+  return nvl_check_launch("nvl_linear_wide");
+}

@@ -50,8 +50,11 @@ __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
     uint32_t* __restrict__ partial, bf16_t* __restrict__ logits_out, int M, int V, int K, int64_t col_offset,
     uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
   constexpr int kRows = MT * 16;
-  constexpr int kStage = kRows * 256;                       // bytes per LDS stage
   constexpr int kCH = (kRows * 16 + kNW * 64 - 1) / (kNW * 64);   // 16-byte x chunks per thread per step
+  // bytes per LDS stage: every thread writes its kCH chunks unconditionally (chunks past the last row land in the
+  // stage's padding, never read) — a lane-divergent guard around the load / LDS write pair makes hipcc wait vmcnt(0)
+  // inside the branch, which drains the weight prefetch ring every step
+  constexpr int kStage = kCH * kNW * 64 * 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
     const int c = tid + i * (kNW * 64);
     int row = c >> 4;
     const int col = c & 15;
-    x_dst[i] = row < kRows ? row * 256 + ((col ^ (row & 15)) << 4) : -1;
+    x_dst[i] = row * 256 + ((col ^ (row & 15)) << 4);       // rows >= kRows: the padding of the stage
     row = row < M ? row : M - 1;                            // padding rows read a valid row (never reported)
     x_src[i] = row * K + col * 8;
   }
@@ -105,8 +108,7 @@ __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
   };
   auto xwrite = [&](int stage) {
 #pragma unroll
-    for (int i = 0; i < kCH; ++i)
-      if (x_dst[i] >= 0) *reinterpret_cast<u32x4_t*>(smem + stage * kStage + x_dst[i]) = xr[i];
+    for (int i = 0; i < kCH; ++i) *reinterpret_cast<u32x4_t*>(smem + stage * kStage + x_dst[i]) = xr[i];
   };
 
   // K is walked in blocks of SB steps whose code is STRAIGHT-LINE (fully unrolled, compile-time guards): hipcc's
@@ -131,17 +133,35 @@ __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
       if (i + RING - 1 < SB) wload(wf[(i + RING - 1) % RING], s0 + i + RING - 1);
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* xs = smem + (i & 1) * kStage;
+      {
+        // fragments of row tile mt + 1 are read from LDS under the MFMAs of tile mt (pinned: hipcc otherwise
+        // re-serialises read -> wait -> NT MFMAs through one register quad)
+        u32x4_t f[2][kKB];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        u32x4_t f[kKB];
+        for (int kb = 0; kb < kKB; ++kb) f[0][kb] = *reinterpret_cast<const u32x4_t*>(xs + frag_off[kb]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int kb = 0; kb < kKB; ++kb) f[kb] = *reinterpret_cast<const u32x4_t*>(xs + mt * 16 * 256 + frag_off[kb]);
+        for (int mt = 0; mt < MT; ++mt) {
+          if (mt + 1 < MT) {
 #pragma unroll
-        for (int kb = 0; kb < kKB; ++kb)
+            for (int kb = 0; kb < kKB; ++kb)
+              f[(mt + 1) & 1][kb] = *reinterpret_cast<const u32x4_t*>(xs + (mt + 1) * 16 * 256 + frag_off[kb]);
+          }
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i % RING][nt][kb]),
-                                                                  __builtin_bit_cast(bf16x8_t, f[kb]), acc[mt][nt], 0, 0, 0);
+          for (int kb = 0; kb < kKB; ++kb)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[i % RING][nt][kb]),
+                                                                    __builtin_bit_cast(bf16x8_t, f[mt & 1][kb]), acc[mt][nt], 0, 0, 0);
+          if (mt + 1 < MT) {
+#pragma unroll
+            for (int j = 0; j < kKB; ++j) {
+              __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // one LDS read ...
+              __builtin_amdgcn_sched_group_barrier(0x008, NT, 0);  // ... per NT MFMAs
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (i + 1 < SB) xwrite((i + 1) & 1);                  // that stage was last read one barrier ago
@@ -271,7 +291,7 @@ template <int MT, int NT, int SB>
 int launch_lm(const LmPlan& p, const void* x, const void* w, const float* temps, uint32_t* partial, void* logits,
               int64_t batch, int64_t vocab, int k, int64_t col_offset, uint64_t seed, uint64_t offset,
               const uint64_t* offset_dev, hipStream_t s) {
-  const size_t lds_x = (size_t)2 * MT * 16 * 256;
+  const size_t lds_x = (size_t)2 * ((MT * 16 * 16 + kNW * 64 - 1) / (kNW * 64)) * kNW * 64 * 16;
   const size_t lds_red = (size_t)kNW * MT * 16 * sizeof(Best);
   const size_t lds = lds_x > lds_red ? lds_x : lds_red;
   static bool attr_done[NVL_MAX_DEVICES] = {};

@@ -28,6 +28,9 @@ SIGNATURES = {
     "nvl_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "nvl_linear_decode_splits": (c_int, [c_int64, c_int, c_int, c_int]),
     "nvl_linear_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "nvl_linear_wide_plan": (c_int, [c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "nvl_linear_wide": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_size_t,
+                                c_void_p]),
     "nvl_add_rmsnorm_splitk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "nvl_silu_mul": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "nvl_rope_neox": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
@@ -207,6 +210,46 @@ def linear_decode(x: torch.Tensor, weight: torch.Tensor, mode: int = LINEAR_BF16
         else:
             out = torch.empty((m, n // 2 if mode == LINEAR_SILU else n), dtype=torch.bfloat16, device=x.device)
     _check(lib().nvl_linear_decode(x.data_ptr(), weight.data_ptr(), out.data_ptr(), m, n, k, mode, _stream()))
+    return out
+
+
+_wide_cache: dict = {}
+
+
+def linear_wide_plan(m: int, n: int, k: int, mode: int) -> tuple[int, int] | None:
+    """(K splits, workspace bytes) of nvl_linear_wide's plan for this shape, or None when it is not covered."""
+    key = (m, n, k, mode)
+    if key not in _wide_cache:
+        splits, ws = ctypes.c_int(0), ctypes.c_size_t(0)
+        ok = lib().nvl_linear_wide_plan(m, n, k, mode, ctypes.byref(splits), ctypes.byref(ws))
+        _wide_cache[key] = (splits.value, ws.value) if ok else None
+    return _wide_cache[key]
+
+
+def linear_wide(x: torch.Tensor, weight: torch.Tensor, mode: int = LINEAR_BF16, out: torch.Tensor | None = None,
+                workspace: torch.Tensor | None = None) -> torch.Tensor:
+    """Deep-K decode linear (same modes as linear_decode). `workspace`: uint8 scratch of the plan's size for
+    modes 0 / 1 when the plan splits K (allocated here when omitted)."""
+    _dev(x, "x")
+    assert x.dim() == 2 and x.is_contiguous() and weight.is_contiguous()
+    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
+    m, k = x.shape
+    n = weight.shape[0]
+    assert weight.shape[1] == k
+    plan = linear_wide_plan(m, n, k, mode)
+    if plan is None:
+        raise NvlError(f"nvl_linear_wide does not cover m={m} n={n} k={k} mode={mode}")
+    splits, ws_bytes = plan
+    if out is None:
+        if mode == LINEAR_PARTIAL:
+            out = torch.empty((splits, m, n), dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty((m, n // 2 if mode == LINEAR_SILU else n), dtype=torch.bfloat16, device=x.device)
+    if ws_bytes and workspace is None:
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+    assert not ws_bytes or workspace.numel() * workspace.element_size() >= ws_bytes
+    _check(lib().nvl_linear_wide(x.data_ptr(), weight.data_ptr(), out.data_ptr(), m, n, k, mode,
+                                 workspace.data_ptr() if ws_bytes else None, ws_bytes, _stream()))
     return out
 
 

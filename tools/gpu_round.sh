@@ -81,6 +81,14 @@ fp8g8)
     timeout 600 python tools/attn_replay.py --fused --hq 8 --hkv 1 --layers 64 --every 16 $f > $OUT/replay_g8$f.json 2> $OUT/replay_g8$f.err; cat $OUT/replay_g8$f.json
     timeout 600 python tools/attn_replay.py --fused --hq 16 --hkv 2 --layers 64 --every 16 $f > $OUT/replay_g8x2$f.json 2> $OUT/replay_g8x2$f.err; cat $OUT/replay_g8x2$f.json
   done;;
+wide)
+  timeout 900 python tools/gemm_wide_bench.py ${WIDE_MODELS:-8b 32b_tp8} > $OUT/gemm_wide${WIDE_TAG:-}.json 2> $OUT/gemm_wide${WIDE_TAG:-}.err; echo "wide rc=$?"; tail -c 800 $OUT/gemm_wide${WIDE_TAG:-}.err; cat $OUT/gemm_wide${WIDE_TAG:-}.json;;
+widex)
+  for cfg in "1 0" "2 2" "1 2" "1 4" "2 4" "2 8"; do
+    set -- $cfg
+    NVL_WIDE_NT=$1 NVL_WIDE_SPLIT=$2 BENCH_M=16,144 timeout 600 python tools/gemm_wide_bench.py ${WIDE_MODELS:-8b} > $OUT/gemm_wide_nt$1_s$2.json 2> $OUT/gemm_wide_nt$1_s$2.err; echo "nt=$1 split=$2 rc=$?"
+    python -c "import json,sys; d=json.load(open('$OUT/gemm_wide_nt$1_s$2.json')); print(d['relerr_max']); [print(' ',k,v) for k,v in d['time_us'].items()]"
+  done;;
 *) echo "unknown step $w";;
 esac
 done
