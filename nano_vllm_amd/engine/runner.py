@@ -696,4 +696,6 @@ class ModelRunner:
                 pool = graph.pool()
             self.graphs[bs] = graph
         torch.cuda.synchronize()
+        from .. import layers
+        layers.release_tuning_scratch()                 # the decode-GEMM choices of every bucket are made by now
         self.graph_pool = pool

@@ -287,20 +287,117 @@ class LinearBase(nn.Module):
         raise NotImplementedError
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if self.bias is None and _decode_sized(x) and ops.linear_decode_splits(
-                x.shape[0], self.weight.shape[0], self.weight.shape[1], ops.LINEAR_BF16):
-            return ops.linear_decode(x, self.weight, ops.LINEAR_BF16)
+        if self.bias is None and _decode_sized(x):
+            y = decode_linear(x, self.weight, ops.LINEAR_BF16)
+            if y is not None:
+                return y
         return F.linear(x, self.weight, self.bias)
 
 
-# Row counts up to this use the hand-written skinny GEMM (nvl_linear_decode); above it the library
-# GEMM wins (measured crossover on MI355X, tools/gemm_bench.py).
+# Row counts up to this use the hand-written decode GEMMs (nvl_linear_decode / nvl_linear_wide); above it the
+# library GEMM wins (measured crossover on MI355X, tools/gemm_bench.py).
 DECODE_LINEAR_MAX_ROWS = 256
 
 
 def _decode_sized(x: torch.Tensor) -> bool:
     return (x.dim() == 2 and x.shape[0] <= DECODE_LINEAR_MAX_ROWS and x.dtype == torch.bfloat16 and x.is_cuda
             and x.is_contiguous())
+
+
+# ---- choice of the decode GEMM ---------------------------------------------------------------------------------
+# K <= 1024 (Qwen3-0.6B): the skinny kernel (nvl_linear_decode), by shape rule. Deep reductions (Qwen3-8B / 32B, full
+# width or per-rank): the wide-tile streaming kernel (nvl_linear_wide) WHERE IT IS FASTER than the library GEMM on this
+# device — decided by timing both once per (rows, n, k, mode) the first time the shape is seen outside a graph capture
+# (the runner's eager warm-up call of every bucket precedes its capture), with the caches flushed before every
+# sample because in the real step every layer's weights come from HBM. NVL_GEMM_WIDE=0 never uses it, =1 always
+# (whenever the plan covers the shape), default "auto".
+_wide_choice: dict[tuple, bool] = {}
+_wide_scratch: dict[tuple, torch.Tensor] = {}
+_flush: dict[int, torch.Tensor] = {}
+
+
+def _scratch(nbytes: int, device: torch.device) -> torch.Tensor | None:
+    """Split-K slab scratch of the wide kernel's bf16 / SiLU modes: one tensor per distinct size, never freed or
+    regrown (captured graphs hold its address)."""
+    if not nbytes:
+        return None
+    key = (nbytes, device.index)
+    t = _wide_scratch.get(key)
+    if t is None:
+        t = _wide_scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return t
+
+
+def _time_cold(fn, device: torch.device, reps: int = 3) -> float:
+    """Best-of GPU time (ms) of fn() with L2 / MALL flushed before every sample. The flush is enqueued first, so the
+    events and fn are already queued when the GPU gets to them (no host gaps inside the bracket)."""
+    buf = _flush.get(device.index)
+    if buf is None:
+        buf = _flush[device.index] = torch.empty(384 << 20, dtype=torch.uint8, device=device)
+    start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = float("inf")
+    for _ in range(reps):
+        buf.zero_()
+        start.record()
+        fn()
+        stop.record()
+        stop.synchronize()
+        best = min(best, start.elapsed_time(stop))
+    return best
+
+
+def release_tuning_scratch() -> None:
+    """Free the cache-flush buffer (called once the graphs are captured)."""
+    _flush.clear()
+
+
+def wide_choices() -> dict:
+    """{(rows, n, k, mode, device): bool} decisions taken so far (diagnostics / bench.py)."""
+    return dict(_wide_choice)
+
+
+def _use_wide(x: torch.Tensor, weight: torch.Tensor, mode: int) -> bool:
+    m, k = x.shape
+    n = weight.shape[0]
+    key = (m, n, k, mode, x.device.index)
+    c = _wide_choice.get(key)
+    if c is not None:
+        return c
+    policy = os.environ.get("NVL_GEMM_WIDE", "auto")   # read when a shape is first seen
+    plan = ops.linear_wide_plan(m, n, k, mode) if policy != "0" else None
+    if plan is None:
+        c = False
+    elif policy == "1":
+        c = True
+    elif torch.cuda.is_current_stream_capturing():
+        return False                                   # an untimed shape inside a capture: library GEMM, not cached
+    else:
+        splits, ws_bytes = plan
+        ws = _scratch(ws_bytes, x.device)
+        out = ops.linear_wide(x, weight, mode, workspace=ws)
+        t_wide = _time_cold(lambda: ops.linear_wide(x, weight, mode, out=out, workspace=ws), x.device)
+        if mode == ops.LINEAR_SILU:
+            t_lib = _time_cold(lambda: ops.silu_mul(F.linear(x, weight)), x.device)
+        else:
+            t_lib = _time_cold(lambda: F.linear(x, weight), x.device)
+        if mode == ops.LINEAR_PARTIAL:                 # the consumer reads S fp32 slabs instead of one bf16 matrix
+            t_wide += (splits * 4 - 2) * m * n / 4e9
+        c = t_wide < 0.97 * t_lib
+    _wide_choice[key] = c
+    return c
+
+
+def decode_linear(x: torch.Tensor, weight: torch.Tensor, mode: int, out: torch.Tensor | None = None):
+    """x [M, K] . weight[N, K]^T on a hand-written decode GEMM, or None when neither kernel takes the shape (the
+    caller keeps the library GEMM). mode as in ops.linear_decode."""
+    m, k = x.shape
+    n = weight.shape[0]
+    if ops.linear_decode_splits(m, n, k, mode):
+        return ops.linear_decode(x, weight, mode, out=out)
+    if _use_wide(x, weight, mode):
+        plan = ops.linear_wide_plan(m, n, k, mode)
+        return ops.linear_wide(x, weight, mode, out=out, workspace=_scratch(plan[1], x.device))
+    return None
 
 
 class ReplicatedLinear(LinearBase):
@@ -338,10 +435,11 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
     def forward_silu(self, x: torch.Tensor) -> torch.Tensor:
         """SiluAndMul(self(x)) for a gate|up pair; on decode-sized inputs the activation is the GEMM's
         epilogue (one launch, no [N, 2*inter] round trip)."""
-        n, k = self.weight.shape
         if (self.bias is None and len(self.output_sizes) == 2 and self.output_sizes[0] == self.output_sizes[1]
-                and _decode_sized(x) and ops.linear_decode_splits(x.shape[0], n, k, ops.LINEAR_SILU)):
-            return ops.linear_decode(x, self.weight, ops.LINEAR_SILU)
+                and _decode_sized(x)):
+            y = decode_linear(x, self.weight, ops.LINEAR_SILU)
+            if y is not None:
+                return y
         return ops.silu_mul(self.forward(x))
 
 
@@ -395,18 +493,17 @@ class RowParallelLinear(LinearBase):
                   all-reduce is fused with the residual-add + RMSNorm)."""
         n, k = self.weight.shape
         if self.tp_size == 1:
-            if (self.bias is None and _decode_sized(x)
-                    and ops.linear_decode_splits(x.shape[0], n, k, ops.LINEAR_PARTIAL)):
-                return ops.linear_decode(x, self.weight, ops.LINEAR_PARTIAL)
+            if self.bias is None and _decode_sized(x):
+                y = decode_linear(x, self.weight, ops.LINEAR_PARTIAL)
+                if y is not None:
+                    return y
             return self.forward(x)
         c = tp.comm()
         if c is not None and self.bias is None and x.dim() == 2 and c.fits(x.shape[0], n):
             # the GEMM writes its partial sums straight into this rank's shared comm region: the all-reduce kernel
             # then starts at its first flag instead of a copy-in phase
             buf = c.input_buffer(x.shape[0], n, x.device)
-            if _decode_sized(x) and ops.linear_decode_splits(x.shape[0], n, k, ops.LINEAR_BF16):
-                ops.linear_decode(x, self.weight, ops.LINEAR_BF16, out=buf)
-            else:
+            if not _decode_sized(x) or decode_linear(x, self.weight, ops.LINEAR_BF16, out=buf) is None:
                 torch.mm(x, self.weight.t(), out=buf)
             return PartialSum(buf)
         return self.forward(x)

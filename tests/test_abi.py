@@ -68,6 +68,15 @@ def test_host_side_argument_validation_without_gpu():
     assert lib.nvl_lmhead_sample_workspace_bytes(300, 151936, 1024) == 0
     assert lib.nvl_linear_decode(16, 16, 16, 144, 6144, 4096, 0, None) == -3 and b"not covered" in lib.nvl_last_error()
     assert lib.nvl_linear_decode(None, 16, 16, 144, 4096, 1024, 0, None) == -1
+    # wide-tile deep-K linear: plan query works without a GPU; uncovered shapes are EUNSUPPORTED, null pointers EINVAL
+    import ctypes
+    sp, ws = ctypes.c_int(0), ctypes.c_size_t(0)
+    assert lib.nvl_linear_wide_plan(144, 6144, 4096, 0, ctypes.byref(sp), ctypes.byref(ws)) == 1
+    assert sp.value >= 1 and ws.value == (sp.value * 144 * 6144 * 4 if sp.value > 1 else 0)
+    assert lib.nvl_linear_wide_plan(144, 4096, 4096, 2, ctypes.byref(sp), ctypes.byref(ws)) == 1 and ws.value == 0
+    assert lib.nvl_linear_wide_plan(144, 6144, 1000, 0, None, None) == 0
+    assert lib.nvl_linear_wide(16, 16, 16, 144, 6144, 1000, 0, None, 0, None) == -3 and b"not covered" in lib.nvl_last_error()
+    assert lib.nvl_linear_wide(None, 16, 16, 144, 6144, 4096, 0, None, 0, None) == -1
     assert lib.nvl_add_rmsnorm_splitk(16, 0, 16, 16, 16, 4, 1024, 1e-6, None) == -1 and b"splits" in lib.nvl_last_error()
 
 

@@ -306,9 +306,17 @@ def _oracle_weights(name, vocab, device="cuda"):
     return cfg, {n: synth_tensor(n, s, 0, device=device).cpu() for n, s in parameter_shapes(cfg).items()}
 
 
+@pytest.mark.parametrize("wide", ["0", "1"])
 @pytest.mark.parametrize("name", ["qwen3-8b-2l", "qwen3-32b-2l"])
-def test_full_width_layers_greedy_parity_vs_oracle(name):
+def test_full_width_layers_greedy_parity_vs_oracle(name, wide, monkeypatch):
+    """Real Qwen3-8B / 32B layer widths (2 layers) against the oracle, with the decode projections on the library GEMM
+    (wide = 0: hipBLASLt + separate SiLU / add-RMSNorm launches) and on nvl_linear_wide (wide = 1: every decode
+    projection, fused SiLU epilogue, split-K slabs into the add-RMSNorm; the engine's default picks per shape by
+    timing)."""
+    from nano_vllm_amd import layers
     from nano_vllm_amd.weights import write_synthetic_checkpoint
+    monkeypatch.setenv("NVL_GEMM_WIDE", wide)
+    layers._wide_choice.clear()
     from oracle.engine import OracleEngine
     from oracle.model import OracleQwen3
     vocab = 2048
@@ -335,8 +343,11 @@ def test_full_width_layers_greedy_parity_vs_oracle(name):
             worst = max(worst, gap)
             exact += gap == 0.0
             total += 1
-    print(f"{name}: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
+    used = sum(layers.wide_choices().values())
+    layers._wide_choice.clear()
+    print(f"{name} wide={wide}: {exact}/{total} exact argmax, worst logit gap {worst:.4f}, wide shapes used {used}")
     assert worst <= TOL and exact >= 0.8 * total
+    assert (used > 0) == (wide == "1")
 
 
 def test_logits_error_vs_exact_arithmetic_is_at_the_reference_floor(tiny_ckpt):

@@ -155,6 +155,88 @@ def test_linear_decode_unsupported_shapes_are_reported(ops):
 
 
 # ------------------------------------------------------------------------------------------
+# wide-tile streaming linears (nvl_linear_wide): the deep-K decode projections of Qwen3-8B / 32B (full width and
+# per-rank TP shapes), same oracle and rounding points as the skinny kernel's tests above. Shapes cover: whole
+# workgroups and ragged last ones (n not a multiple of the workgroup's columns), K splits with a step tail
+# (k / 128 / splits not a multiple of the ring depth), one and two row groups (m > 144), the lm_head shape.
+WIDE_SHAPES = [(6144, 4096), (1280, 5120), (5120, 1024), (1296, 640), (4096, 12288), (48, 128)]
+
+
+@pytest.mark.parametrize("m", [1, 16, 131, 144, 200, 300])
+@pytest.mark.parametrize("n,k", WIDE_SHAPES)
+def test_linear_wide_bf16(ops, m, n, k):
+    x, w, acc = _lin_inputs(m, n, k, 30)
+    plan = ops.linear_wide_plan(m, n, k, ops.LINEAR_BF16)
+    assert plan is not None
+    y = ops.linear_wide(dev(x), dev(w), ops.LINEAR_BF16)
+    assert y.shape == (m, n) and _close_to_rounded(y, acc, atol=1e-4)
+    assert float((ref.bf16_ulp_diff(y.cpu(), acc.to(BF16)) > 0).float().mean()) < 0.02   # order-of-summation flips only
+
+
+@pytest.mark.parametrize("m", [1, 16, 144, 256])
+@pytest.mark.parametrize("n,k", [(24576, 4096), (12800, 5120), (1632, 384)])
+def test_linear_wide_silu(ops, m, n, k):
+    """gate|up projection with SiluAndMul as the epilogue — in-kernel when K is not split, in the slab-reduce kernel
+    when it is (models/qwen3.py:90-113, activation.py:8-11)."""
+    x, w, acc = _lin_inputs(m, n, k, 32)
+    y = ops.linear_wide(dev(x), dev(w), ops.LINEAR_SILU)
+    want = ref.silu_and_mul(acc.to(BF16))
+    assert y.shape == (m, n // 2)
+    d = (y.cpu().float() - want.float()).abs()
+    assert float(d.max()) <= 2e-2 * float(want.float().abs().max())
+    assert float((ref.bf16_ulp_diff(y.cpu(), want) > 1).float().mean()) < 0.02
+
+
+@pytest.mark.parametrize("m", [1, 16, 131, 144, 256])
+@pytest.mark.parametrize("n,k", [(4096, 4096), (4096, 12288), (5120, 3200), (5120, 1024)])
+def test_linear_wide_partials_into_add_rmsnorm(ops, m, n, k):
+    """o_proj / down_proj as fp32 split-K slabs + the fused slab-sum/add/RMSNorm consumer."""
+    x, w, acc = _lin_inputs(m, n, k, 34)
+    splits, ws = ops.linear_wide_plan(m, n, k, ops.LINEAR_PARTIAL)
+    assert splits >= 1 and ws == 0
+    parts = ops.linear_wide(dev(x), dev(w), ops.LINEAR_PARTIAL)
+    assert parts.shape == (splits, m, n) and parts.dtype == torch.float32
+    s = parts.sum(0).cpu()
+    assert float((s - acc).abs().max()) <= 1e-4 * float(acc.abs().max()) + 1e-5
+    r = (torch.randn(m, n, generator=g(36)) * 2).to(BF16)
+    wn = (1 + 0.1 * torch.randn(n, generator=g(37))).to(BF16)
+    seq = parts[0].cpu().clone()                      # slabs summed in split order, like the consumer does
+    for i in range(1, splits):
+        seq += parts[i].cpu()
+    gemm_bf16 = seq.to(BF16)                          # the rounding point of the bf16 GEMM it replaces
+    y_ref, r_ref = ref.add_rms_forward(gemm_bf16, r, wn, 1e-6)
+    dr = dev(r.clone())
+    y = ops.add_rmsnorm_splitk(parts, dr, dev(wn), 1e-6)
+    assert max_ulp(dr, r_ref) <= 1 and max_ulp(y, y_ref) <= 2
+
+
+def test_linear_wide_forced_plans_agree(ops, monkeypatch):
+    """Every (columns per wave, waves, K split) decomposition computes the same product (NVL_WIDE_* force the plan)."""
+    import importlib
+    m, n, k = 131, 2560, 5120
+    x, w, acc = _lin_inputs(m, n, k, 38)
+    for nt, nw, split in [(1, 3, 1), (1, 4, 5), (2, 3, 2), (2, 4, 8), (2, 4, 20)]:
+        monkeypatch.setenv("NVL_WIDE_NT", str(nt))
+        monkeypatch.setenv("NVL_WIDE_NW", str(nw))
+        monkeypatch.setenv("NVL_WIDE_SPLIT", str(split))
+        ops._wide_cache.clear()
+        assert ops.linear_wide_plan(m, n, k, ops.LINEAR_BF16)[0] == split
+        y = ops.linear_wide(dev(x), dev(w), ops.LINEAR_BF16)
+        assert _close_to_rounded(y, acc, atol=1e-4), (nt, nw, split)
+    ops._wide_cache.clear()
+
+
+def test_linear_wide_unsupported_shapes_are_reported(ops):
+    assert ops.linear_wide_plan(16, 4096, 1000, ops.LINEAR_BF16) is None       # K not a multiple of 128
+    assert ops.linear_wide_plan(16, 4100, 1024, ops.LINEAR_BF16) is None       # N not a multiple of 16
+    assert ops.linear_wide_plan(16, 4112, 1024, ops.LINEAR_SILU) is None       # gate|up: N not a multiple of 32
+    x = torch.zeros(16, 1000, dtype=BF16, device="cuda")
+    w = torch.zeros(4096, 1000, dtype=BF16, device="cuda")
+    with pytest.raises(ops.NvlError):
+        ops.linear_wide(x, w, ops.LINEAR_BF16)
+
+
+# ------------------------------------------------------------------------------------------
 def test_rope_bit_exact(ops):
     n, h, hkv = 77, 16, 8
     table = ref.rope_table(128, 4096, 1e6)

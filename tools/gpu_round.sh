@@ -89,6 +89,8 @@ widex)
     NVL_WIDE_NT=$1 NVL_WIDE_SPLIT=$2 BENCH_M=16,144 timeout 600 python tools/gemm_wide_bench.py ${WIDE_MODELS:-8b} > $OUT/gemm_wide_nt$1_s$2.json 2> $OUT/gemm_wide_nt$1_s$2.err; echo "nt=$1 split=$2 rc=$?"
     python -c "import json,sys; d=json.load(open('$OUT/gemm_wide_nt$1_s$2.json')); print(d['relerr_max']); [print(' ',k,v) for k,v in d['time_us'].items()]"
   done;;
+widetests)
+  timeout 900 python -m pytest tests -m gpu -q -rf -x -k "linear_wide or full_width" -s > $OUT/pytest_wide.log 2>&1; echo "wide tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|exact argmax" $OUT/pytest_wide.log | tail -12;;
 *) echo "unknown step $w";;
 esac
 done
