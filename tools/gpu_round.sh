@@ -91,6 +91,14 @@ widex)
   done;;
 widetests)
   timeout 900 python -m pytest tests -m gpu -q -rf -x -k "linear_wide or full_width" -s > $OUT/pytest_wide.log 2>&1; echo "wide tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|exact argmax" $OUT/pytest_wide.log | tail -12;;
+bench8b)
+  for wmode in 0 auto; do
+    NVL_GEMM_WIDE=$wmode timeout 900 python bench.py --model qwen3-8b --no-cpu-baseline --no-roofline > $OUT/bench_8b_wide_$wmode.json 2> $OUT/bench_8b_wide_$wmode.err; echo "bench 8b wide=$wmode rc=$?"; tail -c 300 $OUT/bench_8b_wide_$wmode.err; cut -c1-400 $OUT/bench_8b_wide_$wmode.json; echo
+  done;;
+wideall)
+  WIDE_MODELS="8b 32b 32b_tp4 32b_tp8 lm_head" BENCH_M=16,64,144,256 timeout 900 python tools/gemm_wide_bench.py 8b 32b 32b_tp4 32b_tp8 lm_head > $OUT/gemm_wide_all.json 2> $OUT/gemm_wide_all.err; echo "wideall rc=$?"; tail -c 300 $OUT/gemm_wide_all.err
+  (cd /tmp && BENCH_M=144 timeout 600 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_wide -o wide -- python $REPO/tools/gemm_wide_bench.py 8b 32b_tp8 > $OUT/gemm_wide_under_rocprof.json 2> $OUT/gemm_wide_prof.err; echo "wide prof rc=$?")
+  f=$(find /tmp/prof_wide -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/gemm_wide_kernel_stats.csv && head -8 $OUT/gemm_wide_kernel_stats.csv | cut -c1-160;;
 *) echo "unknown step $w";;
 esac
 done
