@@ -61,7 +61,6 @@ def main():
         t = timeit(lambda: run(x, ws)) / len(ws)
         res[key] += [round(t, 2), round(n * k * 2 / t / 1e3, 1), round(tune_s, 1)]
         print(key, res[key], file=sys.stderr, flush=True)
-    tunable.write_file()
     try:
         res["csv"] = open("/tmp/tunableop.csv").read().splitlines()
     except OSError:
