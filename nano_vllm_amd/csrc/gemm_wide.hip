@@ -35,6 +35,7 @@
 // Rounding points are the reference's: the GEMM output is rounded to bf16 before the activation.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -155,13 +156,19 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
         dst[nt][kb] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[nt] + s * kBK + kb * 32));
   };
 
-  // one k step: the MFMAs of every row tile against the weight set `wfs`, x fragments from LDS stage `xs`.
+  // one k step: the MFMAs of every row tile against the weight set `wfs`, x fragments from LDS stage `xs`; when
+  // `wdst` is given, the weight loads of logical step `sl` are issued INTERLEAVED with the MFMAs (a few per row-tile
+  // group) instead of in one burst at the top of the step: a wave executes in order, so a burst that finds the
+  // memory queue full stalls the MFMAs behind it, and a long MFMA phase leaves the queue unfed.
   // Row tiles go through the matrix pipe in groups of PT (2 independent accumulation chains per group either way);
   // the fragments of group g + 1 are read from LDS under the MFMAs of group g (pinned: hipcc otherwise re-serialises
   // read -> wait -> 2 MFMAs through one register quad).
-  auto compute = [&](const unsigned char* xs, const u32x4_t (*wfs)[kKB]) {
+  auto compute = [&](auto load_tag, const unsigned char* xs, const u32x4_t (*wfs)[kKB], u32x4_t (*wdst)[kKB], int sl) {
+    constexpr bool LOAD = decltype(load_tag)::value;
     constexpr int PT = NT == 1 ? 2 : 1;
     constexpr int NG = (MT + PT - 1) / PT;
+    constexpr int L = NT * kKB;                                   // weight loads per step
+    const int ks = LOAD ? kstep(sl) : 0;
     u32x4_t f[2][PT][kKB];
     auto fread = [&](int g, u32x4_t (*dst)[kKB]) {
 #pragma unroll
@@ -176,6 +183,14 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
+      const int j0 = g * L / NG, j1 = (g + 1) * L / NG;           // this group's share of the step's weight loads
+      if constexpr (LOAD) {
+#pragma unroll
+        for (int j = 0; j < L; ++j)
+          if (j >= j0 && j < j1)
+            wdst[j / kKB][j % kKB] = __builtin_nontemporal_load(
+                reinterpret_cast<const u32x4_t*>(wrow[j / kKB] + ks * kBK + (j % kKB) * 32));
+      }
       if (g + 1 < NG) fread(g + 1, f[(g + 1) & 1]);
 #pragma unroll
       for (int kb = 0; kb < kKB; ++kb)
@@ -188,6 +203,11 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
                   __builtin_bit_cast(bf16x8_t, wfs[nt][kb]), __builtin_bit_cast(bf16x8_t, f[g & 1][t][kb]),
                   acc[g * PT + t][nt], 0, 0, 0);
           }
+      if constexpr (LOAD) {                                       // the group's loads first
+#pragma unroll
+        for (int j = 0; j < L; ++j)
+          if (j >= j0 && j < j1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
       if (g + 1 < NG) {
 #pragma unroll
         for (int j = 0; j < PT * kKB; ++j) {
@@ -209,9 +229,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
 #pragma unroll
     for (int i = 0; i < RING; ++i) {
       const int s = blk * RING + i;
-      wload(wf[(i + RING - 1) % RING], s + RING - 1);             // the weights RING - 1 steps ahead
-      __builtin_amdgcn_sched_barrier(0);
-      compute(smem + (s % 3) * kStage, wf[i]);
+      // the weights RING - 1 steps ahead are requested inside compute()
+      compute(std::true_type{}, smem + (s % 3) * kStage, wf[i], wf[(i + RING - 1) % RING], s + RING - 1);
       __syncthreads();                                            // stage (s + 1) % 3 is staged, stage s % 3 is free
     }
   }
@@ -219,7 +238,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
   for (int i = 0; i < RING - 1; ++i) {
     const int s = nblk * RING + i;
     if (s < steps) {
-      compute(smem + (s % 3) * kStage, wf[i]);
+      compute(std::false_type{}, smem + (s % 3) * kStage, wf[i], nullptr, 0);
       __syncthreads();
     }
   }
