@@ -571,13 +571,13 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 // KV8: the cache holds OCP fp8 e4m3 rows of 128 bytes (opt-in, see decode_stream_fp8_kernel): a tile is loaded as
 // 8 rows x 16 elements per wave instruction and converted (exactly) to bf16 on its way into the wave's LDS tile; the
 // new token's k / v are quantised before they enter this step's softmax. Everything after the LDS write is unchanged.
-template <bool FUSED, bool KV8>
+template <bool FUSED, bool KV8, int G = 8>
 __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
     int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
     int* __restrict__ meta, bf16_t* __restrict__ out, int batch, int hkv, int block_size, int slots,
     float scale_log2e, FusedArgs fa) {
-  constexpr int G = 8;
+  static_assert(G >= 1 && G <= 8, "one 16-column MFMA tile holds the heads of a kv group (padded with zero columns)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int* wsum = reinterpret_cast<int*>(smem_raw + kWaves * kMWaveLds);
   int* pre = wsum + kWaves;  // tile prefix [batch + 1]
@@ -626,6 +626,38 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     f32x4_t oacc[8];
 #pragma unroll
     for (int db = 0; db < 8; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // K/V tile loads run ONE TILE AHEAD of the matrix work: a tile is parked in this wave's LDS region before it is
+    // used, so its registers are free again and take the next tile's loads while the MFMAs / softmax of the current
+    // one run — the first tile's loads are in flight under the q prologue. (A wave that loads, waits, computes,
+    // loads ... leaves the memory queue empty during its compute phases; tools/probes/hbm_pattern_probe.hip reads
+    // the same paged 8 KiB tiles at 6.8 TB/s when nothing else happens between the loads.)
+    constexpr int kTL = KV8 ? kLoads8 : kLoads;
+    u32x4_t kd[kTL], vd[kTL];
+    auto tile_load = [&](int ti) {
+      const int t = ti * kTile;
+      const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
+      if constexpr (KV8) {
+        const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
+        const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
+        const unsigned char* vp = reinterpret_cast<const unsigned char*>(vc) + base;
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i)
+          kd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kp + i * 8 * 128));
+#pragma unroll
+        for (int i = 0; i < kLoads8; ++i)
+          vd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vp + i * 8 * 128));
+      } else {
+        const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
+        const bf16_t* kp = kc + base;
+        const bf16_t* vp = vc + base;
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) kd[i] = load16_nt(kp + i * 4 * 128);
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) vd[i] = load16_nt(vp + i * 4 * 128);
+      }
+    };
+    tile_load(t0);
+    __builtin_amdgcn_sched_barrier(0);
     {
       RopeRegs rr = {};
       u32x4_t wq = {0u, 0u, 0u, 0u}, wk = {0u, 0u, 0u, 0u};
@@ -642,7 +674,8 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
       u32x4_t qh[2];
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
-        qh[it] = *reinterpret_cast<const u32x4_t*>(row + (h * G + rq + 4 * it) * 128 + sub * 8);
+        qh[it] = u32x4_t{0u, 0u, 0u, 0u};
+        if (rq + 4 * it < G) qh[it] = *reinterpret_cast<const u32x4_t*>(row + (h * G + rq + 4 * it) * 128 + sub * 8);
         if constexpr (FUSED) qh[it] = norm_rope_head_regs(qh[it], fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
         *reinterpret_cast<u32x4_t*>(k_lds + (rq + 4 * it) * 256 + sub * 16) = qh[it];   // q tile [8 heads][128]
       }
@@ -709,19 +742,8 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
 
     for (int ti = t0; ti < t0 + run; ++ti) {
       const int t = ti * kTile;
-      const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
+      // registers -> this wave's LDS tile (K in swizzled 16-byte slots, V row-major padded), then the next tile's loads
       if constexpr (KV8) {
-        const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
-        const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
-        const unsigned char* vp = reinterpret_cast<const unsigned char*>(vc) + base;
-        u32x4_t kd[kLoads8], vd[kLoads8];
-#pragma unroll
-        for (int i = 0; i < kLoads8; ++i)
-          kd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kp + i * 8 * 128));
-#pragma unroll
-        for (int i = 0; i < kLoads8; ++i)
-          vd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vp + i * 8 * 128));
-        __builtin_amdgcn_sched_barrier(0);  // all 8 loads in flight before the first use
         // lane holds elements 16 (lane & 7) .. of row 8 i + (lane >> 3): bf16 16-byte chunks c0, c0 + 1 of that row
         const int r8 = lane >> 3, c0 = (lane & 7) * 2;
 #pragma unroll
@@ -741,16 +763,6 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
           *reinterpret_cast<u32x4_t*>(v_lds + rowi * kMVRow + (c0 + 1) * 16) = hi16;
         }
       } else {
-        const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
-        const bf16_t* kp = kc + base;
-        const bf16_t* vp = vc + base;
-        u32x4_t kd[kLoads], vd[kLoads];
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) kd[i] = load16_nt(kp + i * 4 * 128);
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) vd[i] = load16_nt(vp + i * 4 * 128);
-        __builtin_amdgcn_sched_barrier(0);  // all 16 loads in flight before the first use
-        // registers -> this wave's LDS tile: row i*4 + rq; K in swizzled 16-byte slots, V row-major (padded)
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) {
           const int rowi = i * 4 + rq;
@@ -760,6 +772,9 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
         for (int i = 0; i < kLoads; ++i)
           *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
       }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ti + 1 < t0 + run) tile_load(ti + 1);
+      __builtin_amdgcn_sched_barrier(0);
 
       // ---- S^T: two 16-token halves x four 32-dim chunks ------------------------------------------------
       f32x4_t sacc[2];
@@ -886,11 +901,10 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
 
 inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 2; }
 
-template <bool FUSED, bool KV8>
+template <bool FUSED, bool KV8, int G = 8>
 int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                         void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
                         void* workspace, hipStream_t s, const FusedArgs& fa) {
-  constexpr int G = 8;
   const int hq = hkv * G;
   const int slots = stream_slots(max_context);
   float* part_o = (float*)workspace;
@@ -900,7 +914,7 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_kernel<FUSED, KV8>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_kernel<FUSED, KV8, G>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the G = 8 kernel");
       return NVL_ELAUNCH;
@@ -914,7 +928,7 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
   const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
   if (grid > max_wg) grid = max_wg;
   if (grid < 1) grid = 1;
-  hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
+  hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
                      (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
                      block_size, slots, scale * 1.4426950408889634f, fa);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
@@ -988,6 +1002,18 @@ extern "C" size_t nvl_paged_attn_decode_workspace_bytes(int64_t max_batch, int n
 
 namespace {
 
+// Group sizes 2 and 4 also run on the matrix-core kernel (heads padded to one 16-column tile: the matrix pipe is idle
+// anyway, and the tile loads run one tile ahead of the matrix work, which the register-resident packed-dot kernel
+// cannot do without a second tile of registers). NVL_DECODE_MFMA=0 keeps the packed-dot kernels (A/B).
+bool use_mfma_small_g() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("NVL_DECODE_MFMA");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 bool use_valu_g8() {
   static int v = -1;
   if (v < 0) {
@@ -1025,6 +1051,19 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
               : launch_decode_stream_fp8<GG, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,      \
                                                     workspace, s, none);
+    if (use_mfma_small_g() && (G == 2 || G == 4)) {
+#define NVL_MFMA8_G(GG)                                                                                               \
+  if (G == GG)                                                                                                        \
+    return fa ? launch_decode_mfma8<true, true, GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
+                                                    batch, num_kv_heads, block_size, max_context, softmax_scale,      \
+                                                    workspace, s, *fa)                                                \
+              : launch_decode_mfma8<false, true, GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, \
+                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,     \
+                                                     workspace, s, none);
+      NVL_MFMA8_G(2)
+      NVL_MFMA8_G(4)
+#undef NVL_MFMA8_G
+    }
     switch (G) {
       NVL_DECODE8_CASE(1)
       NVL_DECODE8_CASE(2)
@@ -1050,6 +1089,19 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
               : launch_decode_stream<GG, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
                                                 batch, num_kv_heads, block_size, max_context, softmax_scale,      \
                                                 workspace, s, none);
+  if (use_mfma_small_g() && (G == 2 || G == 4)) {
+#define NVL_MFMA_G(GG)                                                                                                \
+  if (G == GG)                                                                                                        \
+    return fa ? launch_decode_mfma8<true, false, GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, \
+                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,     \
+                                                     workspace, s, *fa)                                               \
+              : launch_decode_mfma8<false, false, GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,\
+                                                      batch, num_kv_heads, block_size, max_context, softmax_scale,    \
+                                                      workspace, s, none);
+    NVL_MFMA_G(2)
+    NVL_MFMA_G(4)
+#undef NVL_MFMA_G
+  }
   switch (G) {
     NVL_DECODE_CASE(1)
     NVL_DECODE_CASE(2)

@@ -99,6 +99,17 @@ wideall)
   WIDE_MODELS="8b 32b 32b_tp4 32b_tp8 lm_head" BENCH_M=16,64,144,256 timeout 900 python tools/gemm_wide_bench.py 8b 32b 32b_tp4 32b_tp8 lm_head > $OUT/gemm_wide_all.json 2> $OUT/gemm_wide_all.err; echo "wideall rc=$?"; tail -c 300 $OUT/gemm_wide_all.err
   (cd /tmp && BENCH_M=144 timeout 600 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_wide -o wide -- python $REPO/tools/gemm_wide_bench.py 8b 32b_tp8 > $OUT/gemm_wide_under_rocprof.json 2> $OUT/gemm_wide_prof.err; echo "wide prof rc=$?")
   f=$(find /tmp/prof_wide -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/gemm_wide_kernel_stats.csv && head -8 $OUT/gemm_wide_kernel_stats.csv | cut -c1-160;;
+mfmag2)
+  NVL_DECODE_MFMA=1 timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "decode and not fp8 and not linear" > $OUT/pytest_mfmag2.log 2>&1; echo "mfma small-G tests rc=$?"; tail -3 $OUT/pytest_mfmag2.log
+  for v in 0 1; do
+    NVL_DECODE_MFMA=$v timeout 600 python tools/attn_replay.py --fused > $OUT/replay_mfma$v.json 2> $OUT/replay_mfma$v.err; cat $OUT/replay_mfma$v.json
+    NVL_DECODE_MFMA=$v timeout 600 python tools/attn_replay.py --fused --hq 32 --hkv 8 --layers 36 > $OUT/replay_g4_mfma$v.json 2> $OUT/replay_g4_mfma$v.err; cat $OUT/replay_g4_mfma$v.json
+  done;;
+mfmafp8)
+  timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "decode or fp8" > $OUT/pytest_mfmafp8.log 2>&1; echo "decode+fp8 tests rc=$?"; tail -3 $OUT/pytest_mfmafp8.log
+  for v in 0 1; do
+    NVL_DECODE_MFMA=$v timeout 600 python tools/attn_replay.py --fused --fp8 > $OUT/replay_fp8_mfma$v.json 2> $OUT/replay_fp8_mfma$v.err; cat $OUT/replay_fp8_mfma$v.json
+  done;;
 *) echo "unknown step $w";;
 esac
 done

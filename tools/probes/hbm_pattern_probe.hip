@@ -6,6 +6,9 @@
 // MODE 1  fragment, 1 KiB per row per step (16 instr per tile-step)
 // MODE 2  packed: the same bytes per wave, but the wave's 256 KiB panel is one contiguous run, 1 KiB per instruction
 // MODE 3  row-contiguous: instruction = 4 rows x 256 B (what an LDS-staged W tile load would issue)
+// MODE 4  paged tiles: per iteration a wave reads two 8 KiB contiguous tiles (a K and a V tile of 32 tokens) at
+//         pseudo-random 8-KiB-aligned places of the buffer                          [the decode-attention stream]
+// MODE 5  like 4, but consecutive iterations walk through a 64 KiB block (256-token KV block) before jumping
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
@@ -44,6 +47,29 @@ __global__ __launch_bounds__(NWAVES * 64) void probe(const unsigned char* __rest
         v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(base + off + i * 1024 + lane * 16));
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc ^= v[i];
+    }
+  } else if (MODE == 4 || MODE == 5) {
+    const size_t total = (size_t)rows_per_wave * K_bytes;
+    const size_t span = (size_t)gridDim.x * NWAVES * total;       // whole buffer
+    const size_t half = span / 2;
+    uint32_t hsh = (uint32_t)(blockIdx.x * NWAVES + wave) * 2654435761u + 12345u;
+    size_t blk = 0;
+    for (size_t off = 0; off < total; off += 16384) {
+      const int it = (int)(off / 16384);
+      if (MODE == 4 || (it & 7) == 0) {
+        hsh = hsh * 1664525u + 1013904223u;
+        blk = ((size_t)(hsh >> 8) % (half / 65536)) * 65536;
+      }
+      const size_t t8 = MODE == 4 ? (size_t)((hsh >> 4) & 7) * 8192 : (size_t)(it & 7) * 8192;
+      u32x4_t v[16];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        v[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(w + blk + t8 + i * 1024 + lane * 16));
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        v[8 + i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(w + half + blk + t8 + i * 1024 + lane * 16));
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc ^= v[i];
     }
   } else {
     for (int k = 0; k < K_bytes; k += 256) {
@@ -108,6 +134,11 @@ int main() {
   run<1, 8>("fragment_1KiB_step", w, bytes, K_bytes, 32, sink);
   run<2, 8>("packed_contiguous", w, bytes, K_bytes, 32, sink);
   run<3, 8>("rows4x256B", w, bytes, K_bytes, 32, sink);
+  run<4, 4>("paged_random_8KiB_tiles", w, bytes, K_bytes, 128, sink);
+  run<5, 4>("paged_64KiB_blocks", w, bytes, K_bytes, 128, sink);
+  run<4, 8>("paged_random_8KiB_tiles", w, bytes, K_bytes, 64, sink);
+  run<5, 8>("paged_64KiB_blocks", w, bytes, K_bytes, 64, sink);
+  run<2, 4>("packed_contiguous", w, bytes, K_bytes, 128, sink);
   run<0, 4>("fragment_256B_step", w, bytes, K_bytes, 32, sink);
   run<2, 4>("packed_contiguous", w, bytes, K_bytes, 32, sink);
   run<3, 4>("rows4x256B", w, bytes, K_bytes, 32, sink);
