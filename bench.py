@@ -379,12 +379,17 @@ def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
     hq, hkv, L = geo["heads"], geo["kv_heads"], geo["layers"]
     r = replay(torch, runner.kv_cache, rec["samples"], hq, hkv, runner.config.max_model_len, runner.decode_ws, fused=True)
     achieved = r["achieved_GBps"]
+    # the kernel nvl_paged_attn_decode_fused dispatches to for this geometry (attn_decode.hip: decode_common)
+    G, fp8 = hq // hkv, runner.kv_cache.element_size() == 1
+    if G == 8 or (G in (2, 4) and os.environ.get("NVL_DECODE_MFMA", "1") != "0"):
+        kernel = f"decode_mfma8_kernel<fused, {'fp8' if fp8 else 'bf16'} KV, G={G}>"
+    else:
+        kernel = f"decode_stream_fp8_kernel<{G}, fused>" if fp8 else f"decode_stream_kernel<{G}, fused>"
     step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * runner.kv_cache.element_size() * L
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-            "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"], model),
-            "kernel": ((f"decode_stream_kernel<{hq // hkv}, fused>" if runner.kv_cache.element_size() == 2 else
-                        f"decode_stream_fp8_kernel<{hq // hkv}, fused>") if hq // hkv != 8 else "decode_mfma8_kernel<fused>")
-                      + " + decode_stream_combine_kernel (nvl_paged_attn_decode_fused: the launch the decode step makes)",
+            "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"], model, kernel),
+            "kernel": kernel + " + decode_stream_combine_kernel (nvl_paged_attn_decode_fused: the launch the decode"
+                      " step makes)",
             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],
             "launches_timed": r["launches_timed"], "decode_steps_in_pass": rec["steps"],
             "kv_bytes_read_in_pass": step_bytes, "frac_of_measured_achievable_6.29TBps": achieved / 6290.0}
@@ -424,17 +429,17 @@ def prefill_replay(torch, runner, batches) -> dict:
             "note": "prefill batches of the timed pass (up to 16,384 tokens of 100-1024-token prompts per launch)"}
 
 
-def pmc_traffic(alg_bytes_per_launch: float, model: str = "qwen3-0.6b"):
+def pmc_traffic(alg_bytes_per_launch: float, model: str = "qwen3-0.6b", kernel: str = ""):
     """HBM bytes per launch from the committed rocprofv3 PMC pass of THIS model's decode-attention launches
     (profiles/pmc_traffic.json: FETCH_SIZE summed over the decode_stream_kernel launches of
     tools/attn_replay.py, doubled as MI355X_MICROARCH.md §HBM prescribes for 16 B/lane streaming reads on
     gfx950, divided by the algorithmic bytes of the same launches). PMC counters cannot be read from inside
     this process, so the ratio measured by that separate pass is applied to this run's bytes per launch — it is
-    a property of the kernel's access pattern, not of the run. null when no PMC pass exists for the model."""
+    a property of the kernel's access pattern, not of the run. null when no PMC pass exists for the model / kernel."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             rec = json.load(fh)
-        if rec.get("model", "qwen3-0.6b") != model:
+        if rec.get("model", "qwen3-0.6b") != model or (kernel and not kernel.startswith(rec.get("kernel_name", "?"))):
             return None
         ratio = float(rec["hbm_read_bytes_over_algorithmic"])
     except (OSError, KeyError, ValueError):

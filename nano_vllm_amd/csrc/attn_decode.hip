@@ -604,19 +604,66 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   for (int c = 0; c < 4; ++c) kfrag[c] = head * kMKRow + (((4 * c + quad) ^ head) << 4);
   const int vfrag = (4 * quad + (head >> 2)) * kMVRow + (head & 3) * 8;   // + 32 * db, + 16 rows for the 2nd half
 
-  for (int64_t g = wid * per; g < g1;) {
-    int lo = 0, hi = batch;  // largest b with hkv * pre[b] <= g
+  // global tile index -> (sequence b, its tile count, first global tile of b, kv head h, tile t0 inside (b, h))
+  auto locate = [&](int64_t gg, int& b_, int& nb_, int64_t& base_, int& h_, int& t0_) {
+    int lo = 0, hi = batch;  // largest b with hkv * pre[b] <= gg
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
-      if ((int64_t)pre[mid] * hkv <= g) lo = mid; else hi = mid;
+      if ((int64_t)pre[mid] * hkv <= gg) lo = mid; else hi = mid;
     }
-    const int b = __builtin_amdgcn_readfirstlane(lo);
-    const int nb = __builtin_amdgcn_readfirstlane(pre[b + 1] - pre[b]);
-    const int64_t base_b = (int64_t)__builtin_amdgcn_readfirstlane(pre[b]) * hkv;
-    const int r = (int)(g - base_b);
-    const int h = r / nb;
-    const int t0 = r - h * nb;
+    b_ = __builtin_amdgcn_readfirstlane(lo);
+    nb_ = __builtin_amdgcn_readfirstlane(pre[b_ + 1] - pre[b_]);
+    base_ = (int64_t)__builtin_amdgcn_readfirstlane(pre[b_]) * hkv;
+    const int r = (int)(gg - base_);
+    h_ = r / nb_;
+    t0_ = r - h_ * nb_;
+  };
+  // K/V tile loads run ONE TILE AHEAD of the matrix work, across segment boundaries too: a tile is parked in this
+  // wave's LDS region before it is used, so its registers are free again and take the next tile's loads while the
+  // MFMAs / softmax of the current one run; the first tile of the NEXT (b, h) segment is requested under the last
+  // tile of the current one (a wave sees ~15 tiles in 1-3 segments per launch: a cold start per segment would cost
+  // a full HBM round trip each). A wave that loads, waits, computes, loads ... leaves the memory queue empty during
+  // its compute phases; tools/probes/hbm_pattern_probe.hip reads the same paged 8 KiB tiles at 6.8 TB/s when
+  // nothing else happens between the loads.
+  constexpr int kTL = KV8 ? kLoads8 : kLoads;
+  u32x4_t kd[kTL], vd[kTL];
+  auto tile_load = [&](int bb, int hh, int ti) {
+    const int t = ti * kTile;
+    const int blk = block_tables[(int64_t)bb * bt_stride + t / block_size];
+    if constexpr (KV8) {
+      const int64_t base = (((int64_t)blk * hkv + hh) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
+      const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
+      const unsigned char* vp = reinterpret_cast<const unsigned char*>(vc) + base;
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i)
+        kd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kp + i * 8 * 128));
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i)
+        vd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vp + i * 8 * 128));
+    } else {
+      const int64_t base = (((int64_t)blk * hkv + hh) * block_size + (t % block_size)) * 128 + lane * 8;
+      const bf16_t* kp = kc + base;
+      const bf16_t* vp = vc + base;
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) kd[i] = load16_nt(kp + i * 4 * 128);
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) vd[i] = load16_nt(vp + i * 4 * 128);
+    }
+  };
+
+  bool prefetched = false;   // the first tile of the segment is already in kd / vd (or on its way)
+  for (int64_t g = wid * per; g < g1;) {
+    int b, nb, h, t0;
+    int64_t base_b;
+    locate(g, b, nb, base_b, h, t0);
     const int run = (int)min((int64_t)(nb - t0), g1 - g);
+    if (!prefetched) tile_load(b, h, t0);
+    __builtin_amdgcn_sched_barrier(0);
+    // the segment after this one (its first tile is requested under this segment's last tile)
+    const bool has_next = g + run < g1;
+    int b2 = 0, nb2 = 1, h2 = 0, t02 = 0;
+    int64_t base2 = 0;
+    if (has_next) locate(g + run, b2, nb2, base2, h2, t02);
     const int len = ctx[b];
     const bool owns_last = FUSED && (t0 + run == nb);
 
@@ -626,38 +673,6 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     f32x4_t oacc[8];
 #pragma unroll
     for (int db = 0; db < 8; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    // K/V tile loads run ONE TILE AHEAD of the matrix work: a tile is parked in this wave's LDS region before it is
-    // used, so its registers are free again and take the next tile's loads while the MFMAs / softmax of the current
-    // one run — the first tile's loads are in flight under the q prologue. (A wave that loads, waits, computes,
-    // loads ... leaves the memory queue empty during its compute phases; tools/probes/hbm_pattern_probe.hip reads
-    // the same paged 8 KiB tiles at 6.8 TB/s when nothing else happens between the loads.)
-    constexpr int kTL = KV8 ? kLoads8 : kLoads;
-    u32x4_t kd[kTL], vd[kTL];
-    auto tile_load = [&](int ti) {
-      const int t = ti * kTile;
-      const int blk = block_tables[(int64_t)b * bt_stride + t / block_size];
-      if constexpr (KV8) {
-        const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
-        const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
-        const unsigned char* vp = reinterpret_cast<const unsigned char*>(vc) + base;
-#pragma unroll
-        for (int i = 0; i < kLoads8; ++i)
-          kd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(kp + i * 8 * 128));
-#pragma unroll
-        for (int i = 0; i < kLoads8; ++i)
-          vd[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(vp + i * 8 * 128));
-      } else {
-        const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
-        const bf16_t* kp = kc + base;
-        const bf16_t* vp = vc + base;
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) kd[i] = load16_nt(kp + i * 4 * 128);
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) vd[i] = load16_nt(vp + i * 4 * 128);
-      }
-    };
-    tile_load(t0);
-    __builtin_amdgcn_sched_barrier(0);
     {
       RopeRegs rr = {};
       u32x4_t wq = {0u, 0u, 0u, 0u}, wk = {0u, 0u, 0u, 0u};
@@ -773,7 +788,8 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
           *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (ti + 1 < t0 + run) tile_load(ti + 1);
+      if (ti + 1 < t0 + run) tile_load(b, h, ti + 1);
+      else if (has_next) tile_load(b2, h2, t02);
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- S^T: two 16-token halves x four 32-dim chunks ------------------------------------------------
@@ -845,6 +861,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
       }
     }
     if (lane == 0) meta[b * hkv + h] = (int)((seg0 + nb - 1) / per) - first + 1;   // #partials of (b, h)
+    prefetched = has_next;
     g += run;
   }
 }
