@@ -92,7 +92,7 @@ widex)
 widetests)
   timeout 900 python -m pytest tests -m gpu -q -rf -x -k "linear_wide or full_width" -s > $OUT/pytest_wide.log 2>&1; echo "wide tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|exact argmax" $OUT/pytest_wide.log | tail -12;;
 bench8b)
-  for wmode in 0 auto; do
+  for wmode in ${BENCH8B_MODES:-0 auto}; do
     NVL_GEMM_WIDE=$wmode timeout 900 python bench.py --model qwen3-8b --no-cpu-baseline --no-roofline > $OUT/bench_8b_wide_$wmode.json 2> $OUT/bench_8b_wide_$wmode.err; echo "bench 8b wide=$wmode rc=$?"; tail -c 300 $OUT/bench_8b_wide_$wmode.err; cut -c1-400 $OUT/bench_8b_wide_$wmode.json; echo
   done;;
 wideall)
