@@ -627,9 +627,9 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   // nothing else happens between the loads.
   constexpr int kTL = KV8 ? kLoads8 : kLoads;
   u32x4_t kd[kTL], vd[kTL];
-  auto tile_load = [&](int bb, int hh, int ti) {
+  auto tile_block = [&](int bb, int ti) { return block_tables[(int64_t)bb * bt_stride + (ti * kTile) / block_size]; };
+  auto tile_load = [&](int blk, int hh, int ti) {
     const int t = ti * kTile;
-    const int blk = block_tables[(int64_t)bb * bt_stride + t / block_size];
     if constexpr (KV8) {
       const int64_t base = (((int64_t)blk * hkv + hh) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
       const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
@@ -657,7 +657,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     int64_t base_b;
     locate(g, b, nb, base_b, h, t0);
     const int run = (int)min((int64_t)(nb - t0), g1 - g);
-    if (!prefetched) tile_load(b, h, t0);
+    if (!prefetched) tile_load(tile_block(b, t0), h, t0);
     __builtin_amdgcn_sched_barrier(0);
     // the segment after this one (its first tile is requested under this segment's last tile)
     const bool has_next = g + run < g1;
@@ -757,6 +757,12 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
 
     for (int ti = t0; ti < t0 + run; ++ti) {
       const int t = ti * kTile;
+      // which tile comes next (this segment's, or the first one of the next segment), and its block id: the table
+      // lookup is issued HERE so that its round trip hides under the wait for the current tile
+      const bool in_seg = ti + 1 < t0 + run;
+      const bool has_pf = in_seg || has_next;
+      const int pf_b = in_seg ? b : b2, pf_h = in_seg ? h : h2, pf_t = in_seg ? ti + 1 : t02;
+      const int pf_blk = has_pf ? tile_block(pf_b, pf_t) : 0;
       // registers -> this wave's LDS tile (K in swizzled 16-byte slots, V row-major padded), then the next tile's loads
       if constexpr (KV8) {
         // lane holds elements 16 (lane & 7) .. of row 8 i + (lane >> 3): bf16 16-byte chunks c0, c0 + 1 of that row
@@ -788,8 +794,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
           *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (ti + 1 < t0 + run) tile_load(b, h, ti + 1);
-      else if (has_next) tile_load(b2, h2, t02);
+      if (has_pf) tile_load(pf_blk, pf_h, pf_t);
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- S^T: two 16-token halves x four 32-dim chunks ------------------------------------------------
