@@ -231,260 +231,22 @@ __global__ __launch_bounds__(kNW * 64) void linear_decode_kernel(const bf16_t* _
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// Deep-K variant (Qwen3-8B / 32B projections: K = 4096 ... 25,600, several passes per workgroup).
-// Same decomposition, fragments, LDS image and epilogues as linear_decode_kernel; what changes is the
-// schedule: the (pass, row-tile) loops are FLATTENED into one software pipeline — x tiles stay 2-3
-// tiles ahead across pass boundaries (no pipeline restart per pass) — and the weight fragments of
-// pass k + NSET - 1 are requested at the start of pass k into a spare register set, so a wave always
-// has ~8 KiB of weights in flight: the weight stream never drains, which is what a matrix that is
-// streamed once from HBM needs (8 waves x 8 KiB per workgroup per HBM round trip; 256 workgroups
-// cover the chip's bandwidth-delay product). Loads of a wave retire in order, so x tiles requested
-// behind a weight prefetch wait for it: a pass lasts about one HBM round trip and its MFMAs hide
-// underneath.
-//   NSET = 2, KB = 4: 1024-wide passes, one ahead (row tiles x column tiles <= 16 fit in 256 VGPRs)
-//   NSET = 3, KB = 2:  512-wide passes, two ahead — the same bytes in flight with 40 fewer registers,
-//                      which lets 9 row tiles (M <= 144: the bench's mean batch) x 2 column tiles fit, so
-//                      the matrix is streamed by ONE row group.
-template <int MT, int KB, int NT, int EPI, int NSET>
-__global__ __launch_bounds__(kNW * 64) void linear_decode_multi_kernel(const bf16_t* __restrict__ x,
-                                                                        const bf16_t* __restrict__ w,
-                                                                        void* __restrict__ out, int M, int N, int K,
-                                                                        int ko_iters) {
-  static_assert(EPI != EPI_SILU || NT == 2, "SILU pairs a gate tile with an up tile");
-  constexpr int T = MT * NT;
-  using XT = XTile<KB>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  f32x4_t* red = reinterpret_cast<f32x4_t*>(smem_raw);   // [kNW / 2][T][64]   (after the main loop)
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int l15 = lane & 15, lq = lane >> 4;
-  const int n_tile = blockIdx.x, split = blockIdx.y;
-  const int m_base = blockIdx.z * (MT * 16);
-  const int out_cols = EPI == EPI_SILU ? N / 2 : N;
-  unsigned char* xlds = smem_raw + wave * (2 * XT::kBytes);
-
-  const bf16_t* wrow[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int row = EPI == EPI_SILU ? nt * out_cols + n_tile * 16 + l15 : (n_tile * NT + nt) * 16 + l15;
-    wrow[nt] = w + (int64_t)row * K + lq * 8;
-  }
-  int xoff[KB], wr_off[KB];
-#pragma unroll
-  for (int i = 0; i < KB; ++i) {
-    const int c = i * 64 + lane;
-    const int r = c / XT::kLanesPerRow;
-    const int ccol = c - r * XT::kLanesPerRow;
-    wr_off[i] = r * XT::kStride + ccol * 16;
-    xoff[i] = r * K + ccol * 8;
-  }
-  const int rd_off = l15 * XT::kStride + lq * 16;
-
-  f32x4_t acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
-  const int64_t xlimit = (int64_t)M * K - 8;
-  const int64_t k_wave = ((int64_t)split * ko_iters * kNW + wave) * (KB * 32);   // this wave's k offset in pass 0
-  constexpr int64_t kPassStride = (int64_t)kNW * KB * 32;
-
-  u32x4_t wf[NSET][NT][KB];
-  u32x4_t g[2][KB];
-  auto wload = [&](u32x4_t (*dst)[KB], int ko) {
-    const int64_t kw = k_wave + ko * kPassStride;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-        dst[nt][kb] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[nt] + kw + kb * 32));
-  };
-  // x tile (row tile mt of pass ko); a tile past the last pass reads pass 0 again and is never used
-  auto gload = [&](int mt, int ko, u32x4_t* dst) {
-    const int kk = ko < ko_iters ? ko : 0;
-    const int64_t base = (int64_t)(m_base + mt * 16) * K + k_wave + kk * kPassStride;
-#pragma unroll
-    for (int i = 0; i < KB; ++i) {
-      int64_t off = base + xoff[i];
-      off = off < xlimit ? off : xlimit;
-      dst[i] = *reinterpret_cast<const u32x4_t*>(x + off);
-    }
-  };
-  auto lwrite = [&](int slot, const u32x4_t* src) {
-#pragma unroll
-    for (int i = 0; i < KB; ++i) *reinterpret_cast<u32x4_t*>(xlds + slot * XT::kBytes + wr_off[i]) = src[i];
-  };
-
-  // pipeline invariant before the step of tile t (parity P = t & 1): LDS slot P holds tile t, g[P ^ 1] holds
-  // tile t + 1, g[P] holds tile t + 2.
-#pragma unroll
-  for (int i = 0; i < NSET - 1; ++i)
-    if (i < ko_iters) wload(wf[i], i);
-  gload(0 % MT, 0 / MT, g[0]);
-  gload(1 % MT, 1 / MT, g[1]);
-  __builtin_amdgcn_sched_barrier(0);
-  lwrite(0, g[0]);
-  __builtin_amdgcn_sched_barrier(0);
-  gload(2 % MT, 2 / MT, g[0]);
-  __builtin_amdgcn_sched_barrier(0);
-
-  constexpr int U = (NSET % 2 == 0) ? NSET : 2 * NSET;      // passes per unrolled group: set index and tile parity static
-  auto pass = [&](auto idx_tag, int ko) {
-    constexpr int IDX = decltype(idx_tag)::value;          // ko mod U
-    constexpr int SET = IDX % NSET;
-    if (ko + NSET - 1 < ko_iters) wload(wf[(SET + NSET - 1) % NSET], ko + NSET - 1);   // wave-uniform branch
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int P = (IDX * MT + mt) & 1;                    // compile-time after unrolling (U is even)
-      u32x4_t f[KB];
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-        f[kb] = *reinterpret_cast<const u32x4_t*>(xlds + P * XT::kBytes + rd_off + kb * 64);
-      __builtin_amdgcn_sched_barrier(0);
-      lwrite(P ^ 1, g[P ^ 1]);
-      __builtin_amdgcn_sched_barrier(0);
-      gload((mt + 3) % MT, ko + (mt + 3) / MT, g[P ^ 1]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, wf[SET][nt][kb]),
-                                                                __builtin_bit_cast(bf16x8_t, f[kb]), acc[mt][nt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-  for (int ko = 0; ko < ko_iters; ko += U) {
-    pass(std::integral_constant<int, 0>{}, ko);
-    if (ko + 1 < ko_iters) pass(std::integral_constant<int, 1 % U>{}, ko + 1);
-    if constexpr (U > 2) {
-      if (ko + 2 < ko_iters) pass(std::integral_constant<int, 2 % U>{}, ko + 2);
-      if (ko + 3 < ko_iters) pass(std::integral_constant<int, 3 % U>{}, ko + 3);
-      if (ko + 4 < ko_iters) pass(std::integral_constant<int, 4 % U>{}, ko + 4);
-      if (ko + 5 < ko_iters) pass(std::integral_constant<int, 5 % U>{}, ko + 5);
-    }
-  }
-  __syncthreads();   // all waves are done with their tile rings: the LDS is reused for the merge
-
-  constexpr int HW = kNW / 2;
-  if (wave >= HW) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) red[((wave - HW) * T + mt * NT + nt) * 64 + lane] = acc[mt][nt];
-  }
-  __syncthreads();
-  if (wave < HW) {
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        f32x4_t* slot = red + (wave * T + mt * NT + nt) * 64 + lane;
-        *slot = acc[mt][nt] + *slot;
-      }
-  }
-  __syncthreads();
-
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    if ((mt % kNW) != wave) continue;
-    f32x4_t v[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      v[nt] = red[(mt * NT + nt) * 64 + lane];
-#pragma unroll
-      for (int ww = 1; ww < HW; ++ww) v[nt] += red[(ww * T + mt * NT + nt) * 64 + lane];
-    }
-    const int m = m_base + mt * 16 + l15;
-    if (m >= M) continue;
-    if constexpr (EPI == EPI_BF16) {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = (n_tile * NT + nt) * 16 + lq * 4;
-        u32x2_t o = {pack_bf16x2(v[nt][0], v[nt][1]), pack_bf16x2(v[nt][2], v[nt][3])};
-        *reinterpret_cast<u32x2_t*>((bf16_t*)out + (int64_t)m * N + n) = o;
-      }
-    } else if constexpr (EPI == EPI_SILU) {
-      const int n = n_tile * 16 + lq * 4;
-      float o[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) o[i] = silu_f32(round_bf16(v[0][i])) * round_bf16(v[1][i]);
-      u32x2_t ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-      *reinterpret_cast<u32x2_t*>((bf16_t*)out + (int64_t)m * out_cols + n) = ov;
-    } else {
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const int n = (n_tile * NT + nt) * 16 + lq * 4;
-        *reinterpret_cast<f32x4_t*>((float*)out + ((int64_t)split * M + m) * N + n) = v[nt];
-      }
-    }
-  }
-}
-
 
 struct Plan {
   int kb, ko, split, nt, mt, mgroups;
-  bool deep;
 };
 
-// Deep-K shapes (several passes per workgroup) are reported as NOT covered unless NVL_GEMM_MULTI=1: measured on
-// MI355X (profiles/r02_gemm_deep_*.json) linear_decode_multi_kernel is correct on every Qwen3-8B / 32B shape but
-// beats hipBLASLt only on a few of them (8B qkv at M = 144: 30.9 vs 40.2 us; 32B down: 176 vs 209 us) and loses
-// on the rest (8B gate_up: 89.7 vs 56.9 us). Cause: with 32 output columns per workgroup every workgroup re-reads
-// all of x — 768 workgroups x 144 x 4096 x 2 B = 906 MB of L2 traffic for 201 MB of weights — and a wave keeps
-// only 2-3 x tiles (4-6 KiB) in flight, so the kernel runs at L2 latency, not at HBM bandwidth. The fix is a
-// different decomposition (x tile shared through LDS by waves that split N, stream-K across workgroups), not a
-// tuning of this one; until then the caller keeps the library GEMM for these shapes.
-bool multi_enabled() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("NVL_GEMM_MULTI");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v == 1;
-}
-int deep_kb() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("NVL_GEMM_DEEP_KB");
-    v = (e && e[0] == '4') ? 4 : 2;
-  }
-  return v;
-}
-
+// Deep-K shapes (several passes of the per-wave K range: Qwen3-8B / 32B projections) are reported as NOT covered: with
+// 16-32 output columns per workgroup every workgroup re-reads all of x (768 workgroups x 144 x 4096 x 2 B = 906 MB of
+// L2 traffic for 201 MB of weights on the 8B gate_up), which a multi-pass variant of this kernel ran at 1.6-2.2 TB/s
+// (profiles/r02_gemm_deep_*.json, removed). Those shapes belong to the wide-tile kernel (gemm_wide.hip).
 // K range per wave = K / (split * 8) must be KB * KO * 32 with KB in {1, 2, 3, 4}.
 bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
   const int out_cols = mode == EPI_SILU ? n / 2 : n;
   if (m < 1 || m > 4096 || n < 16 || k < 256 || out_cols % 16 || (mode == EPI_SILU && n % 32)) return false;
   const int tiles = out_cols / 16;
   const int mtiles = (int)((m + 15) / 16);
-  const bool deep = k > 4096 || (k > 1024 && mode != EPI_PARTIAL) || (k > 3072 && mode == EPI_PARTIAL);
-  if (deep) {
-    // Weights dominate: ONE row group whenever the accumulators fit (a second group would stream the matrix
-    // twice), two column tiles per workgroup, K split across workgroups (fp32 slabs) only to reach ~256 of them.
-    if (!multi_enabled()) return false;
-    const int nt = (mode == EPI_SILU || tiles % 2 == 0) ? 2 : 1;
-    const int kb = deep_kb();                             // 2: 512-wide passes, two ahead; 4: 1024-wide, one ahead
-    const int mt_max = nt == 2 ? (kb == 2 ? 9 : 6) : 16;
-    const int mgroups = (mtiles + mt_max - 1) / mt_max;
-    const int col_wgs = mode == EPI_SILU ? tiles : tiles / nt;
-    const int pass_k = kNW * kb * 32;
-    int split = 1;
-    if (mode == EPI_PARTIAL)
-      while (split < 8 && col_wgs * mgroups * split * 2 <= 320 && k % (split * 2 * pass_k) == 0) split *= 2;
-    if (k % (split * pass_k)) return false;
-    p->deep = true;
-    p->kb = kb;
-    p->ko = k / (split * pass_k);
-    p->split = split;
-    p->nt = nt;
-    p->mgroups = mgroups;
-    p->mt = (mtiles + mgroups - 1) / mgroups;
-    return p->ko >= 1;
-  }
+  if (k > 4096 || (k > 1024 && mode != EPI_PARTIAL) || (k > 3072 && mode == EPI_PARTIAL)) return false;   // deep K
   // two column tiles per workgroup (every x fragment feeds 2 MFMAs) and M split in >= 2 groups once there
   // are enough rows: halves the x bytes a CU ingests at the same workgroup count
   int nt = 1;
@@ -508,7 +270,6 @@ bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
     if (kw % c == 0) { kb = c; break; }
   if (!kb) return false;
   if (kw / kb > 1) return false;                  // (shallow shapes are single-pass by construction)
-  p->deep = false;
   p->kb = kb;
   p->ko = kw / kb;
   p->split = split;
@@ -538,47 +299,6 @@ int launch(const void* x, const void* w, void* out, int64_t m, int n, int k, con
   hipLaunchKernelGGL((linear_decode_kernel<MT, KB, NT, EPI>), dim3(col_wgs, p.split, p.mgroups), dim3(kNW * 64), lds,
                      s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.ko);
   return nvl_check_launch("nvl_linear_decode");
-}
-
-template <int MT, int NT, int EPI, int KB, int NSET>
-int launch_multi(const void* x, const void* w, void* out, int64_t m, int n, int k, const Plan& p, hipStream_t s) {
-  const size_t lds_red = (size_t)(kNW / 2) * MT * NT * 64 * sizeof(f32x4_t);
-  const size_t lds_ring = (size_t)kNW * 2 * XTile<KB>::kBytes;
-  const size_t lds = lds_red > lds_ring ? lds_red : lds_ring;
-  static bool attr_done[NVL_MAX_DEVICES] = {};
-  bool& attr_set = attr_done[nvl_device_slot()];
-  if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_decode_multi_kernel<MT, KB, NT, EPI, NSET>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      nvl_set_error("nvl_linear_decode: cannot reserve %zu B of LDS", lds);
-      return NVL_ELAUNCH;
-    }
-    attr_set = true;
-  }
-  const int out_cols = EPI == EPI_SILU ? n / 2 : n;
-  const int col_wgs = EPI == EPI_SILU ? out_cols / 16 : out_cols / 16 / NT;
-  hipLaunchKernelGGL((linear_decode_multi_kernel<MT, KB, NT, EPI, NSET>), dim3(col_wgs, p.split, p.mgroups),
-                     dim3(kNW * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.ko);
-  return nvl_check_launch("nvl_linear_decode");
-}
-
-template <int NT, int EPI>
-int dispatch_multi(const void* x, const void* w, void* out, int64_t m, int n, int k, const Plan& p, hipStream_t s) {
-#define NVL_MT_CASE(V)                                                                                    \
-  case V:                                                                                                 \
-    if constexpr (V * NT <= 18) {                                                                         \
-      if (p.kb == 2) return launch_multi<V, NT, EPI, 2, 3>(x, w, out, m, n, k, p, s);                     \
-      if constexpr (V * NT <= 12) return launch_multi<V, NT, EPI, 4, 2>(x, w, out, m, n, k, p, s);        \
-    }                                                                                                     \
-    break;
-  switch (p.mt) {
-    NVL_MT_CASE(1) NVL_MT_CASE(2) NVL_MT_CASE(3) NVL_MT_CASE(4) NVL_MT_CASE(5) NVL_MT_CASE(6) NVL_MT_CASE(7)
-    NVL_MT_CASE(8) NVL_MT_CASE(9) NVL_MT_CASE(10) NVL_MT_CASE(11) NVL_MT_CASE(12) NVL_MT_CASE(13) NVL_MT_CASE(14)
-    NVL_MT_CASE(15) NVL_MT_CASE(16)
-  }
-#undef NVL_MT_CASE
-  nvl_set_error("nvl_linear_decode: internal plan error (deep, mt=%d nt=%d kb=%d)", p.mt, NT, p.kb);
-  return NVL_EINVAL;
 }
 
 template <int KB, int NT, int EPI>
@@ -734,14 +454,6 @@ extern "C" int nvl_linear_decode(const void* x, const void* weight, void* out, i
     return NVL_EUNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
-  if (p.deep) {
-    if (mode == EPI_SILU) return dispatch_multi<2, EPI_SILU>(x, weight, out, m, n, k, p, s);
-    if (mode == EPI_BF16)
-      return p.nt == 2 ? dispatch_multi<2, EPI_BF16>(x, weight, out, m, n, k, p, s)
-                       : dispatch_multi<1, EPI_BF16>(x, weight, out, m, n, k, p, s);
-    return p.nt == 2 ? dispatch_multi<2, EPI_PARTIAL>(x, weight, out, m, n, k, p, s)
-                     : dispatch_multi<1, EPI_PARTIAL>(x, weight, out, m, n, k, p, s);
-  }
   if (mode == EPI_SILU) return dispatch_kb<2, EPI_SILU>(x, weight, out, m, n, k, p, s);
   if (mode == EPI_BF16)
     return p.nt == 2 ? dispatch_kb<2, EPI_BF16>(x, weight, out, m, n, k, p, s)

@@ -61,7 +61,7 @@ def test_host_side_argument_validation_without_gpu():
     assert lib.nvl_linear_decode_splits(144, 4096, 1024, 0) == 1
     assert lib.nvl_linear_decode_splits(144, 1024, 2048, 2) == 4
     assert lib.nvl_linear_decode_splits(144, 6144, 1024, 1) == 1
-    assert lib.nvl_linear_decode_splits(144, 6144, 4096, 0) == 0          # deep-K shapes: opt-in (NVL_GEMM_MULTI=1)
+    assert lib.nvl_linear_decode_splits(144, 6144, 4096, 0) == 0          # deep-K shapes: not this kernel's (nvl_linear_wide)
     # collectives: a communicator must be created and connected first; lm_head sampler reports uncovered shapes
     assert lib.nvl_allreduce_run(None, 16, 16, 4, 1024, None) == -1
     assert lib.nvl_lmhead_sample_workspace_bytes(131, 151936, 1024) == 594 * 131 * 8

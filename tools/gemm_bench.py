@@ -1,6 +1,5 @@
 """Skinny decode-linear micro-benchmark + correctness vs an fp32 reference; prints one JSON line."""
 import json, os, sys
-os.environ.setdefault("NVL_GEMM_MULTI", "1")      # this tool measures the opt-in deep-K kernel too
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn.functional as F
@@ -69,7 +68,6 @@ for name, n, k, mode in shapes:
         if ops.linear_decode_splits(m, n, k, mode):
             res["relerr"][f"{name}_m{m}"] = check(m, n, k, mode)
 res["relerr_max"] = max(res["relerr"].values()) if res["relerr"] else None
-res["deep_kb"] = os.environ.get("NVL_GEMM_DEEP_KB", "2")
 
 res["time_us"] = {}
 for m in ((16, 32, 64, 96, 144, 208, 256, 512) if model == "0.6b" else (16, 64, 144, 256)):

@@ -29,11 +29,6 @@ probe)
   timeout 600 python tools/gpu_probe.py > $OUT/probe.log 2>&1; cp gpurun_out/probe.json $OUT/ 2>/dev/null; tail -3 $OUT/probe.log;;
 gemm)
   timeout 600 python tools/gemm_bench.py > $OUT/gemm_bench.json 2> $OUT/gemm_bench.err; echo "gemm rc=$?"; tail -c 1500 $OUT/gemm_bench.err; cat $OUT/gemm_bench.json;;
-gemmx)
-  for spec in "8b 2" "8b 4" "32b 2" "lm_head 2" "32b_tp8 2" "32b_tp4 2"; do
-    set -- $spec
-    NVL_GEMM_DEEP_KB=$2 timeout 600 python tools/gemm_bench.py $1 > $OUT/gemm_$1_kb$2.json 2> $OUT/gemm_$1_kb$2.err; echo "gemm $1 kb$2 rc=$?"; tail -c 400 $OUT/gemm_$1_kb$2.err; cat $OUT/gemm_$1_kb$2.json; echo
-  done;;
 retest)
   timeout 1200 python -m pytest tests/test_tp_gpu.py tests/test_kernels_gpu.py -m gpu -q -rf -k "tp2 or long or continuation or shards or linear_decode or p2p" > $OUT/pytest_retest.log 2>&1; echo "retest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_retest.log | tail -20;;
 lmhead)
