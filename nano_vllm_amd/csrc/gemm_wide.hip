@@ -349,6 +349,7 @@ double wide_cost(int64_t m, int n, int k, int mode, const WidePlan& p) {
 
 bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
   if (m < 1 || m > 1024 || n < 16 || k < kBK || k % kBK) return false;
+  if (m * (int64_t)k >= (1ll << 31) || (int64_t)n * k >= (1ll << 40)) return false;   // 32-bit x element offsets in the loader
   if (mode == EPI_SILU ? n % 32 : n % 16) return false;
   const int out_cols = mode == EPI_SILU ? n / 2 : n;
   const int mtiles = (int)((m + 15) / 16);
