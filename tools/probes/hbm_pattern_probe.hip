@@ -134,6 +134,10 @@ int main() {
   run<1, 8>("fragment_1KiB_step", w, bytes, K_bytes, 32, sink);
   run<2, 8>("packed_contiguous", w, bytes, K_bytes, 32, sink);
   run<3, 8>("rows4x256B", w, bytes, K_bytes, 32, sink);
+  // the decode-attention launch of the bench: 512 workgroups x 4 waves, ~15 tiles of 16 KiB per wave, 512 MB in total
+  run<4, 4>("paged_random_8KiB_tiles_512MB_launch", w, (size_t)512 << 20, K_bytes, 32, sink);
+  run<5, 4>("paged_64KiB_blocks_512MB_launch", w, (size_t)512 << 20, K_bytes, 32, sink);
+  run<2, 4>("packed_contiguous_512MB_launch", w, (size_t)512 << 20, K_bytes, 32, sink);
   run<4, 4>("paged_random_8KiB_tiles", w, bytes, K_bytes, 128, sink);
   run<5, 4>("paged_64KiB_blocks", w, bytes, K_bytes, 128, sink);
   run<4, 8>("paged_random_8KiB_tiles", w, bytes, K_bytes, 64, sink);
