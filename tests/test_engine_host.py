@@ -272,3 +272,45 @@ def test_control_channel_ring_order_backpressure_and_payloads():
     for rx in rxs:
         rx.close()
     tx.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# layers.decode_linear: which GEMM a decode-sized linear runs on (host logic; the kernels are stubbed)
+def test_decode_gemm_chooser_policies(monkeypatch):
+    """Skinny kernel by shape rule; else the wide-tile kernel according to NVL_GEMM_WIDE (0: never even planned,
+    1: whenever the plan covers the shape, auto: timed once per shape outside a capture — inside a capture an
+    untimed shape keeps the library GEMM and the decision is NOT cached); None = caller keeps the library GEMM."""
+    from nano_vllm_amd import layers, ops
+    calls = []
+    monkeypatch.setattr(ops, "linear_decode_splits", lambda m, n, k, mode: 1 if k <= 1024 else 0)
+    monkeypatch.setattr(ops, "linear_decode", lambda x, w, mode, out=None: calls.append("skinny") or "skinny")
+    monkeypatch.setattr(ops, "linear_wide_plan", lambda m, n, k, mode: calls.append("plan") or ((2, 64) if n != 48 else None))
+    monkeypatch.setattr(ops, "linear_wide", lambda x, w, mode, out=None, workspace=None: calls.append("wide") or "wide")
+    monkeypatch.setattr(layers, "_scratch", lambda nbytes, device: None)
+    monkeypatch.setattr(layers, "_wide_choice", {})
+    x, shallow, deep, uncovered = torch.zeros(16, 1024), torch.zeros(64, 1024), torch.zeros(64, 4096), torch.zeros(48, 4096)
+    xd = torch.zeros(16, 4096)
+
+    assert layers.decode_linear(x, shallow, ops.LINEAR_BF16) == "skinny" and calls == ["skinny"]
+    calls.clear()
+    monkeypatch.setenv("NVL_GEMM_WIDE", "0")
+    assert layers.decode_linear(xd, deep, ops.LINEAR_BF16) is None and calls == []          # never planned
+    layers._wide_choice.clear()
+    monkeypatch.setenv("NVL_GEMM_WIDE", "1")
+    assert layers.decode_linear(xd, deep, ops.LINEAR_SILU) == "wide"
+    assert layers.decode_linear(xd, uncovered, ops.LINEAR_BF16) is None                     # plan says no
+    assert layers.wide_choices()[(16, 64, 4096, ops.LINEAR_SILU, None)] is True
+    calls.clear()
+    assert layers.decode_linear(xd, deep, ops.LINEAR_SILU) == "wide" and calls == ["plan", "wide"]   # decision cached
+    # auto: timed outside a capture, deferred (not cached) inside one
+    layers._wide_choice.clear()
+    monkeypatch.setenv("NVL_GEMM_WIDE", "auto")
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
+    assert layers.decode_linear(xd, deep, ops.LINEAR_PARTIAL) is None and layers.wide_choices() == {}
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    times = iter([1.0, 2.0])                                                               # wide 1.0 ms, library 2.0 ms
+    monkeypatch.setattr(layers, "_time_cold", lambda fn, device, reps=3: next(times))
+    assert layers.decode_linear(xd, deep, ops.LINEAR_BF16) == "wide"
+    times = iter([2.0, 1.0])
+    assert layers.decode_linear(xd, deep, ops.LINEAR_SILU) is None                          # library GEMM is faster
+    assert layers.wide_choices() == {(16, 64, 4096, ops.LINEAR_BF16, None): True, (16, 64, 4096, ops.LINEAR_SILU, None): False}
