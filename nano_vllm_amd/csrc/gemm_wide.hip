@@ -17,14 +17,20 @@
 //     conflict-free ds_read_b128 B fragments) while the consumers work on step s; three LDS stages, one barrier
 //     per step.
 //   * Consumers stream their W fragments HBM -> VGPR with non-temporal loads through a RING-deep register ring
-//     (the loads of step s + RING - 1 are issued at the start of step s): (RING - 1) x NT x 4 KiB in flight per
-//     wave. The x loads live in a DIFFERENT wave because a wave's loads retire in order: in the first version every
+//     (the loads of step s + RING - 1 are issued during step s, a few per row-tile group between the MFMAs):
+//     (RING - 1) x NT x 4 KiB in flight per wave. The x loads live in a DIFFERENT wave because a wave's loads retire in order: in the first version every
 //     wave loaded x chunks too, and waiting for the x of step s + 1 (an L2 hit) also waited for every older weight
 //     load, i.e. the ring was drained to its newest set at every step (~18 GB/s per CU whatever RING was).
 //   * The K loop's body is RING steps of straight-line code with UNCONDITIONAL (index-clamped) prefetches and
 //     unconditional uses, so both edges into the loop header carry the same outstanding-load pattern and hipcc's
 //     s_waitcnt stays counted; a load whose only use sits under a branch is sunk into it and becomes synchronous
 //     (both seen in the .s of earlier versions). The steps % RING tail runs after the loop on the ring's loaded sets.
+//   * What the time is made of (measured): a CU's memory path is the saturated resource; it
+//     moves ~18.6 GB/s of fragment-shaped weight loads and ~67 GB/s of row-contiguous x tiles, and the two ADD:
+//     T = W bytes per CU / 18.6 GB/s + x bytes per CU / 67 GB/s (8B gate_up at 144 rows: 42 + 18 us). Hence ~256 equal
+//     workgroups first (every CU streams), then as many columns per workgroup as that allows (fewer x re-reads).
+//   * Workgroups start their K walk at different steps (kstep): rows of W are K * 2 bytes apart, lock-step walkers
+//     would all hit the same offset of an 8-16 KiB stride at once.
 //   * Small-N shapes (qkv / o / down, and everything per-rank under TP) do not have ~256 column tiles: K is split
 //     over workgroups as well (grid.y) and the partial tiles leave as fp32 slabs [split][M][N]. For o_proj / down_proj
 //     the consumer (nvl_add_rmsnorm_splitk) sums the slabs in its prologue ("reduce at the launch boundary"); for
