@@ -11,7 +11,14 @@
 // second tiny kernel merges the slots. The grid is a launch-time constant, so the same captured
 // launch serves any mix of lengths; padded rows (context_len 0) contribute no tiles.
 //
-// Data path: K and V tiles go HBM -> VGPR directly with non-temporal loads (each byte is used
+// Three kernels share this bookkeeping, the split-partial format and the merge kernel:
+//   decode_stream_kernel      packed-dot (VALU) scores straight from registers — group size 1 (and 2 / 4 / 8 with
+//                             NVL_DECODE_MFMA=0 / NVL_DECODE_G8_VALU=1); described in the next paragraphs
+//   decode_mfma8_kernel       scores and P.V on the matrix cores through a per-wave LDS tile, K/V loads one tile
+//                             ahead of the matrix work — group sizes 2, 4, 8, bf16 or fp8 cache (the default there)
+//   decode_stream_fp8_kernel  fp8 cache on the packed-dot path — group size 1 (and 2 / 4 with NVL_DECODE_MFMA=0)
+//
+// Data path (packed-dot kernel): K and V tiles go HBM -> VGPR directly with non-temporal loads (each byte is used
 // exactly once; an LDS round trip would be pure overhead, and `nt` measured +8 % bandwidth). One
 // wave instruction fetches 4 token rows x 256 B = 1 KiB contiguous (head-major cache layout),
 // 16 instructions (16 KiB) are in flight per wave before the first use. Lane (rq = lane>>4,
