@@ -241,26 +241,40 @@ def run_tp_external(args, torch, dist, rank, world, tp):
 
 def tp_extra(args, torch, dist, rank, world, primary) -> dict | None:
     """BASELINE's second metric next to the data-parallel line of a multi-GPU run: Qwen3-32B with
-    tensor_parallel_size = world, one cold pass. Guarded: whatever happens here, the primary line is printed."""
-    import copy
-    import threading
-    a = copy.copy(args)
-    a.model, a.steps, a.warmup, a.no_roofline, a.no_cpu_baseline = "qwen3-32b", 1, 0, True, True
-
-    def bail():                       # every rank: a hung collective must not outlive the primary measurement
-        if rank == 0:
-            primary["tp_qwen3_32b"] = {"error": "timed out"}
-            print(json.dumps(primary), flush=True)
-        os._exit(0)
-    watchdog = threading.Timer(float(os.environ.get("NVL_BENCH_TP_EXTRA_TIMEOUT", "900")) + (0 if rank == 0 else 5), bail)
-    watchdog.daemon = True
-    watchdog.start()
+    tensor_parallel_size = world, one cold pass — run as a SEPARATE job: every rank starts a child
+    `bench.py --tp world --model qwen3-32b` and the children form their own process group on another port. The
+    TP path has only ever run with all ranks on ONE GPU; a fault of its hipIpc P2P kernels on real links must not
+    take the data-parallel measurement down with it, and a hang ends at the timeout (the children are killed).
+    Whatever happens here, the primary line is printed."""
+    import gc
+    import subprocess
+    gc.collect()
+    torch.cuda.empty_cache()                       # the replica's engine has exited: hand the GPU to the child
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(1024 + (int(env.get("MASTER_PORT", "29500")) + 101 - 1024) % 60000)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # the children rendezvous among themselves (rank 0 child hosts the store)
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--tp", str(world), "--model", "qwen3-32b",
+           "--steps", "1", "--warmup", "0", "--num-seqs", str(args.num_seqs), "--no-roofline", "--no-cpu-baseline",
+           "--no-tp-extra", "--gpu-memory-utilization", str(args.gpu_memory_utilization),
+           "--num-kvcache-blocks", str(args.num_kvcache_blocks), "--kv-cache-dtype", args.kv_cache_dtype]
+    if args.eager:
+        cmd.append("--eager")
+    timeout = float(os.environ.get("NVL_BENCH_TP_EXTRA_TIMEOUT", "900"))
     try:
-        r = run_tp_external(a, torch, dist, rank, world, world)
+        cp = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout:.0f} s"} if rank == 0 else None
     except Exception as ex:  # noqa: BLE001 — a secondary measurement must never sink the bench line
-        r = {"error": repr(ex)}
-    watchdog.cancel()
-    return r
+        return {"error": repr(ex)} if rank == 0 else None
+    if rank != 0:
+        return None
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    if cp.returncode != 0 or not lines:
+        return {"error": f"child exit code {cp.returncode}", "stderr_tail": cp.stderr[-600:]}
+    try:
+        return json.loads(lines[-1])
+    except ValueError as ex:
+        return {"error": repr(ex)}
 
 
 def run_replica(args, torch, dist, rank, world, tp, backend):
@@ -342,7 +356,7 @@ def run_replica(args, torch, dist, rank, world, tp, backend):
         result["roofline"]["decode_step"] = decode_step_roofline(runner, rec, result, host["prefill_steps_s"])
         if rec.get("prefill"):
             result["roofline_prefill"] = prefill_replay(torch, runner, rec["prefill"])
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # a reported baseline: N = 1 runs only
         try:
             result["cpu_baseline"] = cpu_baseline(torch, llm, args.model, prompts, out_lens)
         except Exception as ex:  # noqa: BLE001 — a reported baseline must never sink the bench line

@@ -105,6 +105,11 @@ mfmafp8)
   for v in 0 1; do
     NVL_DECODE_MFMA=$v timeout 600 python tools/attn_replay.py --fused --fp8 > $OUT/replay_fp8_mfma$v.json 2> $OUT/replay_fp8_mfma$v.err; cat $OUT/replay_fp8_mfma$v.json
   done;;
+tprun1)
+  # only the data-parallel line + the Qwen3-32B TP extra (a separate child job per rank), both ranks on the ONE GPU
+  export NVL_BENCH_SHARE_GPU=1 NVL_BENCH_BACKEND=gloo NVL_BENCH_TP_EXTRA_TIMEOUT=400
+  timeout 700 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 0 --num-seqs 48 --gpu-memory-utilization 0.3 --num-kvcache-blocks 300 --no-cpu-baseline --no-roofline > $OUT/torchrun_dp2_plus_tp_extra.json 2> $OUT/torchrun_dp2.err; echo "torchrun dp2+extra rc=$?"; grep -v "socket.cpp\|Gloo\|amdgpu.ids\|OMP_NUM\|\*\*\*" $OUT/torchrun_dp2.err | tail -8; cut -c1-2500 $OUT/torchrun_dp2_plus_tp_extra.json
+  unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND NVL_BENCH_TP_EXTRA_TIMEOUT;;
 *) echo "unknown step $w";;
 esac
 done
