@@ -314,3 +314,44 @@ def test_decode_gemm_chooser_policies(monkeypatch):
     times = iter([2.0, 1.0])
     assert layers.decode_linear(xd, deep, ops.LINEAR_SILU) is None                          # library GEMM is faster
     assert layers.wide_choices() == {(16, 64, 4096, ops.LINEAR_BF16, None): True, (16, 64, 4096, ops.LINEAR_SILU, None): False}
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py: the Qwen3-32B TP extra of a multi-GPU run is a child job; its outcome can never sink the primary line
+def test_bench_tp_extra_child_job_outcomes(monkeypatch):
+    import json as _json
+    import subprocess
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    args = types.SimpleNamespace(num_seqs=48, gpu_memory_utilization=0.3, num_kvcache_blocks=300, kv_cache_dtype="bf16",
+                                 eager=False)
+    fake_torch = types.SimpleNamespace(cuda=types.SimpleNamespace(empty_cache=lambda: None))
+    seen = {}
+
+    def fake_run(cmd, env, capture_output, text, timeout):
+        seen.update(cmd=cmd, env=env, timeout=timeout)
+        return subprocess.CompletedProcess(cmd, 0, stdout='noise\n{"metric": "x", "value": 1.5}\n', stderr="")
+
+    monkeypatch.setenv("MASTER_PORT", "29533")
+    monkeypatch.setenv("TORCHELASTIC_USE_AGENT_STORE", "True")
+    monkeypatch.setenv("NVL_BENCH_TP_EXTRA_TIMEOUT", "77")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    r = bench.tp_extra(args, fake_torch, None, 0, 4, {})
+    assert r == {"metric": "x", "value": 1.5}
+    assert seen["env"]["MASTER_PORT"] == "29634" and "TORCHELASTIC_USE_AGENT_STORE" not in seen["env"] and seen["timeout"] == 77.0
+    cmd = seen["cmd"]
+    assert cmd[1].endswith("bench.py") and cmd[cmd.index("--tp") + 1] == "4" and cmd[cmd.index("--model") + 1] == "qwen3-32b"
+    assert "--no-tp-extra" in cmd and "--no-cpu-baseline" in cmd and "--eager" not in cmd
+    assert bench.tp_extra(args, fake_torch, None, 1, 4, {}) is None                           # only rank 0 reports
+    # a crashed child, a child without a JSON line, a timeout: reported as an error dict on rank 0
+    monkeypatch.setattr(subprocess, "run", lambda *a, **k: subprocess.CompletedProcess(a, -11, stdout="", stderr="boom"))
+    r = bench.tp_extra(args, fake_torch, None, 0, 4, {})
+    assert r["error"] == "child exit code -11" and r["stderr_tail"] == "boom"
+
+    def timing_out(cmd, **k):
+        raise subprocess.TimeoutExpired(cmd, k["timeout"])
+    monkeypatch.setattr(subprocess, "run", timing_out)
+    assert "timed out" in bench.tp_extra(args, fake_torch, None, 0, 4, {})["error"]
+    assert bench.tp_extra(args, fake_torch, None, 2, 4, {}) is None
+    _json.dumps(r)
