@@ -465,22 +465,40 @@ class P2PComm:
 
     def __init__(self, rank: int, world: int, max_bytes: int, exchange, barrier):
         self.rank, self.world = rank, world
-        h = c_void_p()
-        _check(lib().nvl_allreduce_create(rank, world, max_bytes, ctypes.byref(h)))
-        self._h = h
+        self._h = None
+        self._views: dict[tuple, torch.Tensor] = {}
+        # Every rank takes part in the exchange AND in the barrier whatever happened locally: a rank that raised
+        # before them would leave its peers waiting inside a collective it never joins. A rank that could not
+        # create its communicator publishes an all-zero token, which makes every peer fail the same way.
+        err: Exception | None = None
+        none = b"\0" * 64
         uid = ctypes.create_string_buffer(64)
-        _check(lib().nvl_allreduce_uid(self._h, uid))
-        uids = exchange(uid.raw)
-        assert len(uids) == world and all(len(u) == 64 for u in uids)
-        blob = ctypes.create_string_buffer(b"".join(uids), 64 * world)
-        _check(lib().nvl_allreduce_connect(self._h, blob))
+        try:
+            h = c_void_p()
+            _check(lib().nvl_allreduce_create(rank, world, max_bytes, ctypes.byref(h)))
+            self._h = h
+            _check(lib().nvl_allreduce_uid(self._h, uid))
+        except Exception as ex:  # noqa: BLE001 — re-raised after the collectives below
+            err = ex
+        uids = exchange(uid.raw if err is None else none)
+        if err is None:
+            try:
+                assert len(uids) == world and all(len(u) == 64 for u in uids)
+                if any(u == none for u in uids):
+                    raise NvlError("nvl_allreduce: a peer could not create its communicator")
+                blob = ctypes.create_string_buffer(b"".join(uids), 64 * world)
+                _check(lib().nvl_allreduce_connect(self._h, blob))
+            except Exception as ex:  # noqa: BLE001
+                err = ex
         barrier()
+        if err is not None:
+            self.close()
+            raise err
         self.max_bytes = int(lib().nvl_allreduce_max_bytes(self._h))
         # Hand-off flavour: lean by default (per-wave store drains; the shared buffer is uncached, so an acknowledged
         # store is in memory and a load cannot hit a stale line); NVL_TP_P2P_FENCES=1 adds the system-scope
         # release / acquire fences back (14.7 -> 8.7 us per 131 x 5120 all-reduce without them, profiles/r02_p2p_bench_w2.json)
         _check(lib().nvl_allreduce_set_fences(self._h, 1 if os.environ.get("NVL_TP_P2P_FENCES", "0") == "1" else 0))
-        self._views: dict[tuple, torch.Tensor] = {}
 
     def input_buffer(self, rows: int, hidden: int, device) -> torch.Tensor:
         """A [rows, hidden] bf16 tensor that IS this rank's shared input region: a GEMM that writes its output

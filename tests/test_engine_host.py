@@ -355,3 +355,70 @@ def test_bench_tp_extra_child_job_outcomes(monkeypatch):
     assert "timed out" in bench.tp_extra(args, fake_torch, None, 0, 4, {})["error"]
     assert bench.tp_extra(args, fake_torch, None, 2, 4, {}) is None
     _json.dumps(r)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ops.P2PComm construction is collective: a rank that fails locally must still join the exchange and the barrier
+class _FakeCommLib:
+    def __init__(self, fail_create=False, fail_connect=False):
+        self.fail_create, self.fail_connect = fail_create, fail_connect
+        self.calls = []
+
+    def nvl_last_error(self):
+        return b"fake failure"
+
+    def nvl_allreduce_create(self, rank, world, max_bytes, href):
+        self.calls.append("create")
+        return -4 if self.fail_create else 0
+
+    def nvl_allreduce_uid(self, h, uid):
+        self.calls.append("uid")
+        uid.raw = bytes([7]) * 64
+        return 0
+
+    def nvl_allreduce_connect(self, h, blob):
+        self.calls.append("connect")
+        return -4 if self.fail_connect else 0
+
+    def nvl_allreduce_max_bytes(self, h):
+        return 1 << 20
+
+    def nvl_allreduce_set_fences(self, h, on):
+        self.calls.append(f"fences={on}")
+        return 0
+
+    def nvl_allreduce_destroy(self, h):
+        self.calls.append("destroy")
+        return 0
+
+
+@pytest.mark.parametrize("mode", ["ok", "create_fails", "connect_fails", "peer_failed"])
+def test_p2p_comm_construction_always_joins_its_collectives(mode, monkeypatch):
+    from nano_vllm_amd import ops
+    fake = _FakeCommLib(fail_create=mode == "create_fails", fail_connect=mode == "connect_fails")
+    monkeypatch.setattr(ops, "lib", lambda: fake)
+    monkeypatch.delenv("NVL_TP_P2P_FENCES", raising=False)
+    joined = []
+
+    def exchange(blob):
+        joined.append(("exchange", blob))
+        peer = b"\0" * 64 if mode == "peer_failed" else bytes([9]) * 64
+        return [blob, peer]
+
+    def barrier():
+        joined.append(("barrier",))
+
+    if mode == "ok":
+        c = ops.P2PComm(0, 2, 1 << 20, exchange, barrier)
+        assert c.max_bytes == 1 << 20 and fake.calls == ["create", "uid", "connect", "fences=0"]
+        assert c.fits(16, 1024) and not c.fits(16, 1028)
+        c.close()
+        assert fake.calls[-1] == "destroy"
+    else:
+        with pytest.raises(ops.NvlError):
+            ops.P2PComm(0, 2, 1 << 20, exchange, barrier)
+        assert "fences=0" not in fake.calls
+        if mode == "create_fails":
+            assert joined[0] == ("exchange", b"\0" * 64)          # an all-zero token tells the peers
+            assert "connect" not in fake.calls
+    assert [j[0] for j in joined] == ["exchange", "barrier"]      # both collectives, exactly once, in every outcome
