@@ -79,3 +79,58 @@ def test_tiny_model_logits_match_reference(compiled):
                         block_tables=torch.tensor([[2, -1], [0, 3]], dtype=torch.int32))
             logits = m.compute_logits(m.forward(ids, pos, meta), meta)
             assert (logits.float() - g[f"decode{step}_logits"].float()).abs().max() <= floor
+
+
+def test_sampler_matches_reference_sampler_module():
+    """oracle.ops.sampler_forward vs the reference's Sampler module (layers/sampler.py:8-12, eager, CPU generator
+    seeded with make_golden.SAMPLER_SEED): the sampled ids of three consecutive calls are identical — same
+    exponential draws in the same order, same clamp, same argmax of p / E."""
+    from oracle.make_golden import SAMPLER_SEED
+    g = load_file(os.path.join(GOLDEN, "sampler_eager.safetensors"))
+    gen = torch.Generator().manual_seed(SAMPLER_SEED)
+    for call in range(3):
+        got = ref.sampler_forward(g["logits"], g["temps"], gen)
+        assert torch.equal(got, g[f"tokens{call}"]), call
+    # the log-space form the HIP kernel evaluates (argmax of l / T - log E) picks the same ids given the same E
+    gen = torch.Generator().manual_seed(SAMPLER_SEED)
+    probs_shape = g["logits"].shape
+    e = torch.empty(probs_shape).exponential_(1, generator=gen)
+    assert torch.equal(ref.sampler_keys(g["logits"], g["temps"], e).argmax(-1), g["tokens0"])
+    assert int(g["tokens0"][5]) == 77 and int(g["tokens2"][5]) == 77      # the certain row
+
+
+def test_engine_run_matches_reference_engine():
+    """A free-running OracleEngine (eager rounding) reproduces, step for step, a multi-step run of the reference's own
+    Scheduler + BlockManager + Sequence + Qwen3ForCausalLM (tests/golden/engine_tiny.json.gz, written by
+    oracle/make_golden.py::gen_engine_tiny): batch composition, scheduled / cached token counts, block tables and the
+    greedy token ids, through chunked prefill, prefix-cache hits and a preemption by recompute."""
+    import gzip
+    import json
+    import tempfile
+    from nano_vllm_amd.weights import write_synthetic_checkpoint
+    from oracle.engine import OracleEngine
+    from oracle.make_golden import ENGINE_CFG, engine_workload
+    from oracle.model import OracleQwen3, load_weights
+    with gzip.open(os.path.join(GOLDEN, "engine_tiny.json.gz"), "rt") as fh:
+        golden = json.load(fh)
+    path = tempfile.mkdtemp(prefix="qwen3tiny_")
+    write_synthetic_checkpoint(path, "qwen3-tiny", seed=0, vocab_size=512, max_position_embeddings=2048)
+    cfg, w = load_weights(path)
+    eng = OracleEngine(OracleQwen3(cfg, w, compiled=False), ENGINE_CFG["num_kvcache_blocks"],
+                       ENGINE_CFG["kvcache_block_size"], ENGINE_CFG["max_num_seqs"],
+                       ENGINE_CFG["max_num_batched_tokens"], ENGINE_CFG["eos"])
+    eng.keep_logits = True
+    prompts, max_tokens = engine_workload()
+    seqs = [eng.add(p, 0.0, m, True) for p, m in zip(prompts, max_tokens)]
+    for i, want in enumerate(golden[:-1]):
+        eng.step()
+        got = eng.trace[-1]
+        assert got["is_prefill"] == want["prefill"], i
+        assert got["seq_ids"] == want["seqs"] and got["sched"] == want["sched"] and got["cached"] == want["cached"], i
+        assert got["tables"] == want["tables"], i
+        assert got["tokens"] == want["tokens"], (i, got["tokens"], want["tokens"])
+        assert max(abs(a - b) for a, b in zip(got["margin"], want["margin"])) <= 1e-6, i   # logits identical (the golden is rounded to 6 digits)
+        sums = got["logits"].sum(-1).tolist()
+        assert max(abs(a - b) for a, b in zip(sums, want["logit_sum"])) <= 1e-3, i
+    assert not eng.waiting and not eng.running
+    assert [s["toks"][s["n_prompt"]:] for s in seqs] == golden[-1]["final"]
