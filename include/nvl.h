@@ -192,7 +192,14 @@ int nvl_qknorm_rope_kvstore(const void* qkv, int64_t qkv_tok_stride,
  * (-1 padded, engine/model_runner.py:125). HBM-bound: reads
  * context_len * 2 * Hkv * 256 bytes per sequence.
  * Workspace holds split-KV partials; size from the _workspace_bytes query
- * (depends on max_context, not on the per-step lengths => graph-safe). */
+ * (depends on max_context, not on the per-step lengths => graph-safe).
+ * plan (optional, may be NULL): the per-step work plan written by
+ *   nvl_decode_plan for the SAME (context_lens, batch, Hq, Hkv, max_context);
+ *   with it the kernel skips its own prefix scan / search (the plan is the same
+ *   for every layer of a decode step: make it once, pass it to every layer).
+ * lse (optional, may be NULL): fp32 [batch, Hq] log-sum-exp of the scaled
+ *   scores, natural log — flash-attn's `softmax_lse` (return_softmax_lse=True);
+ *   -inf for padded rows. */
 size_t nvl_paged_attn_decode_workspace_bytes(int64_t max_batch, int num_q_heads,
                                              int64_t max_context);
 int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cache,
@@ -203,7 +210,20 @@ int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
                           int block_size, int64_t num_blocks, int64_t max_context,
                           float softmax_scale,
                           void* workspace, size_t workspace_bytes,
-                          int kv_dtype, void* stream);
+                          int kv_dtype, const void* plan, float* lse, void* stream);
+
+/* Per-step plan of the decode attention launches: where every wave of the
+ * attention grid starts in the step's flattened (sequence, kv-head, 32-token
+ * tile) work list. Depends only on context_lens / batch / head counts /
+ * max_context / the device, i.e. it is identical for all layers of a decode
+ * step (the reference calls flash_attn_with_kvcache once per layer,
+ * layers/attention.py:72-74, and each call re-derives its own split
+ * schedule). Enqueue-only, graph-capturable; `plan` is caller-owned,
+ * nvl_decode_plan_bytes() bytes, 16-byte aligned. */
+size_t nvl_decode_plan_bytes(void);
+int nvl_decode_plan(const int32_t* context_lens, int64_t batch,
+                    int num_q_heads, int num_kv_heads, int64_t max_context,
+                    void* plan, size_t plan_bytes, void* stream);
 
 /* Decode-step fusion of the three reference launches that precede the attention
  * call on a decode step — q/k RMSNorm (models/qwen3.py:82-84), rotary embedding
@@ -227,7 +247,7 @@ int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stride,
                                 int block_size, int64_t num_blocks, int64_t max_context,
                                 float softmax_scale,
                                 void* workspace, size_t workspace_bytes,
-                                int kv_dtype, void* stream);
+                                int kv_dtype, const void* plan, float* lse, void* stream);
 
 /* ---- Varlen causal prefill attention (MFMA) ----------------------------------
  * Replaces flash_attn_varlen_func as called at layers/attention.py:67-70:
@@ -240,7 +260,9 @@ int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stride,
  *   block_tables != NULL : k, v are the paged caches (layout at the top),
  *                          block_tables [num_seqs, bt_stride] (prefix cache /
  *                          chunked prefill continuation).
- * cu_seqlens_q / cu_seqlens_k: int32 [num_seqs + 1] (device). */
+ * cu_seqlens_q / cu_seqlens_k: int32 [num_seqs + 1] (device).
+ * lse (optional, may be NULL): fp32 [sum Lq, Hq] log-sum-exp of the scaled
+ * scores, natural log (flash-attn's softmax_lse). */
 int nvl_attn_prefill_varlen(const void* q, const void* k, const void* v,
                             int64_t k_tok_stride, int64_t v_tok_stride,
                             const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k,
@@ -249,7 +271,7 @@ int nvl_attn_prefill_varlen(const void* q, const void* k, const void* v,
                             int64_t total_q, int num_seqs, int max_seqlen_q,
                             int num_q_heads, int num_kv_heads,
                             int block_size, int64_t num_blocks,
-                            float softmax_scale, int kv_dtype, void* stream);
+                            float softmax_scale, int kv_dtype, float* lse, void* stream);
 
 /* ---- Token sampler ---------------------------------------------------------
  * Replaces Sampler.forward (layers/sampler.py:7-12):

@@ -96,6 +96,60 @@ __device__ __forceinline__ void chunk_prefix(const int32_t* __restrict__ ctx, in
 // (b, h) by max_context / (32 * 4) + 2 — the workspace size is therefore static.
 constexpr int kMinTilesPerWave = 4;
 
+// ---------------------------------------------------------------------------------------------------
+// Per-STEP plan (nvl_decode_plan): the flattening above depends only on (context_lens, Hkv, grid), which are the same
+// for every layer of a decode step, yet every workgroup of every layer's launch recomputed it — a coalesced read of
+// context_lens, a 256-thread prefix scan with two barriers, and a binary search per wave, ~2 us between launch and the
+// first K/V byte requested, 28 times per step on Qwen3-0.6B. One tiny kernel per step now writes, for every wave of
+// the attention grid, where its share starts; the attention kernel reads ONE 16-byte record through the scalar cache
+// and goes. Later segments of a wave's share need no search at all: they always start at tile 0 of the next
+// (sequence, kv-head) pair, and the tile count of a sequence is ceil(context_len / 32).
+struct PlanHeader {          // 32 bytes, followed by nwaves PlanEntry records
+  int64_t total;             // tiles of the whole step = hkv * sum_b ceil(len_b / 32)
+  int64_t per;               // tiles per wave
+  int32_t nwaves, batch, hkv, pad;
+};
+struct __attribute__((aligned(16))) PlanEntry { int32_t b, h, t0, nb; };   // first segment of a wave's share (b < 0: none)
+
+__global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restrict__ ctx, int batch, int hkv, int nwaves,
+                                                          PlanHeader* __restrict__ hdr) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  int* wsum = reinterpret_cast<int*>(smem_raw);
+  int* pre = wsum + kWaves;
+  chunk_prefix(ctx, batch, kTile, pre, wsum);
+  __syncthreads();
+  const int64_t total = (int64_t)pre[batch] * hkv;
+  int64_t per = (total + nwaves - 1) / nwaves;
+  if (per < kMinTilesPerWave) per = kMinTilesPerWave;
+  if (threadIdx.x == 0) {
+    hdr->total = total;
+    hdr->per = per;
+    hdr->nwaves = nwaves;
+    hdr->batch = batch;
+    hdr->hkv = hkv;
+    hdr->pad = 0;
+  }
+  PlanEntry* ent = reinterpret_cast<PlanEntry*>(hdr + 1);
+  for (int w = threadIdx.x; w < nwaves; w += 256) {
+    const int64_t g = (int64_t)w * per;
+    PlanEntry e = {-1, 0, 0, 0};
+    if (g < total) {
+      int lo = 0, hi = batch;  // largest b with hkv * pre[b] <= g
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if ((int64_t)pre[mid] * hkv <= g) lo = mid; else hi = mid;
+      }
+      const int nb = pre[lo + 1] - pre[lo];
+      const int r = (int)(g - (int64_t)pre[lo] * hkv);
+      e.b = lo;
+      e.nb = nb;
+      e.h = r / nb;
+      e.t0 = r - e.h * nb;
+    }
+    ent[w] = e;
+  }
+}
+
 // streamed-once data: non-temporal load (does not displace q / block tables / partials in L2)
 __device__ __forceinline__ u32x4_t load16_nt(const bf16_t* p) {
   return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
@@ -583,7 +637,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
     int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
     int* __restrict__ meta, bf16_t* __restrict__ out, int batch, int hkv, int block_size, int slots,
-    float scale_log2e, FusedArgs fa) {
+    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan) {
   static_assert(G >= 1 && G <= 8, "one 16-column MFMA tile holds the heads of a kv group (padded with zero columns)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int* wsum = reinterpret_cast<int*>(smem_raw + kWaves * kMWaveLds);
@@ -596,13 +650,23 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   unsigned char* k_lds = smem_raw + wave * kMWaveLds;
   unsigned char* v_lds = k_lds + kTile * kMKRow;
 
-  chunk_prefix(ctx, batch, kTile, pre, wsum);
-  __syncthreads();
-  const int64_t total = (int64_t)pre[batch] * hkv;
-  const int64_t nwaves = (int64_t)gridDim.x * kWaves;
-  int64_t per = (total + nwaves - 1) / nwaves;
-  if (per < kMinTilesPerWave) per = kMinTilesPerWave;
   const int64_t wid = (int64_t)blockIdx.x * kWaves + wave;
+  int64_t total, per;
+  PlanEntry first_seg = {-1, 0, 0, 0};
+  if (plan != nullptr) {
+    // per-step plan: header + this wave's record, two scalar loads (the addresses are wave-uniform); no LDS prefix,
+    // no barrier, no search
+    total = plan->total;
+    per = plan->per;
+    first_seg = reinterpret_cast<const PlanEntry*>(plan + 1)[wid];
+  } else {
+    chunk_prefix(ctx, batch, kTile, pre, wsum);
+    __syncthreads();
+    total = (int64_t)pre[batch] * hkv;
+    const int64_t nwaves = (int64_t)gridDim.x * kWaves;
+    per = (total + nwaves - 1) / nwaves;
+    if (per < kMinTilesPerWave) per = kMinTilesPerWave;
+  }
   const int64_t g1 = min(total, (wid + 1) * per);
 
   // loop-invariant LDS byte offsets
@@ -611,8 +675,10 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   for (int c = 0; c < 4; ++c) kfrag[c] = head * kMKRow + (((4 * c + quad) ^ head) << 4);
   const int vfrag = (4 * quad + (head >> 2)) * kMVRow + (head & 3) * 8;   // + 32 * db, + 16 rows for the 2nd half
 
-  // global tile index -> (sequence b, its tile count, first global tile of b, kv head h, tile t0 inside (b, h))
-  auto locate = [&](int64_t gg, int& b_, int& nb_, int64_t& base_, int& h_, int& t0_) {
+  // global tile index -> (sequence b, its tile count, kv head h, tile t0 inside (b, h)); only the FIRST segment of a
+  // wave's share needs this search (from the plan when there is one): every later segment starts at tile 0 of the
+  // next (sequence, kv-head) pair — see `advance`
+  auto locate = [&](int64_t gg, int& b_, int& nb_, int& h_, int& t0_) {
     int lo = 0, hi = batch;  // largest b with hkv * pre[b] <= gg
     while (hi - lo > 1) {
       const int mid = (lo + hi) >> 1;
@@ -620,10 +686,25 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     }
     b_ = __builtin_amdgcn_readfirstlane(lo);
     nb_ = __builtin_amdgcn_readfirstlane(pre[b_ + 1] - pre[b_]);
-    base_ = (int64_t)__builtin_amdgcn_readfirstlane(pre[b_]) * hkv;
-    const int r = (int)(gg - base_);
+    const int r = (int)(gg - (int64_t)__builtin_amdgcn_readfirstlane(pre[b_]) * hkv);
     h_ = r / nb_;
     t0_ = r - h_ * nb_;
+  };
+  // the pair after (b_, h_): next kv-head of the same sequence, or head 0 of the next sequence that has tiles
+  // (context_len 0 = graph padding). Only called when tiles remain (g + run < g1 <= total), so the scan terminates.
+  auto advance = [&](int b_, int nb_, int h_, int& b2_, int& nb2_, int& h2_) {
+    if (h_ + 1 < hkv) {
+      b2_ = b_; nb2_ = nb_; h2_ = h_ + 1;
+      return;
+    }
+    int bb = b_ + 1, n = 0;
+    while (bb < batch) {
+      const int len2 = __builtin_amdgcn_readfirstlane(ctx[bb]);
+      n = len2 > 0 ? (len2 + kTile - 1) / kTile : 0;
+      if (n > 0) break;
+      ++bb;
+    }
+    b2_ = bb; nb2_ = n; h2_ = 0;
   };
   // K/V tile loads run ONE TILE AHEAD of the matrix work, across segment boundaries too: a tile is parked in this
   // wave's LDS region before it is used, so its registers are free again and take the next tile's loads while the
@@ -659,18 +740,26 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   };
 
   bool prefetched = false;   // the first tile of the segment is already in kd / vd (or on its way)
+  int b = 0, nb = 1, h = 0, t0 = 0;
+  if (wid * per < g1) {
+    if (plan != nullptr) {
+      b = __builtin_amdgcn_readfirstlane(first_seg.b);
+      nb = __builtin_amdgcn_readfirstlane(first_seg.nb);
+      h = __builtin_amdgcn_readfirstlane(first_seg.h);
+      t0 = __builtin_amdgcn_readfirstlane(first_seg.t0);
+    } else {
+      locate(wid * per, b, nb, h, t0);
+    }
+  }
   for (int64_t g = wid * per; g < g1;) {
-    int b, nb, h, t0;
-    int64_t base_b;
-    locate(g, b, nb, base_b, h, t0);
     const int run = (int)min((int64_t)(nb - t0), g1 - g);
     if (!prefetched) tile_load(tile_block(b, t0), h, t0);
     __builtin_amdgcn_sched_barrier(0);
-    // the segment after this one (its first tile is requested under this segment's last tile)
+    // the segment after this one (its first tile is requested under this segment's last tile); it starts at tile 0
     const bool has_next = g + run < g1;
-    int b2 = 0, nb2 = 1, h2 = 0, t02 = 0;
-    int64_t base2 = 0;
-    if (has_next) locate(g + run, b2, nb2, base2, h2, t02);
+    int b2 = 0, nb2 = 1, h2 = 0;
+    constexpr int t02 = 0;
+    if (has_next) advance(b, nb, h, b2, nb2, h2);
     const int len = ctx[b];
     const bool owns_last = FUSED && (t0 + run == nb);
 
@@ -857,7 +946,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     }
 
     // ---- emit: lane (head, quad) holds O[head][16 db + 4 quad + r]; l is a per-quad partial -------------------
-    const int64_t seg0 = base_b + (int64_t)h * nb;
+    const int64_t seg0 = g - t0;                                     // first global tile of (b, h)
     const int first = (int)(seg0 / per);
     const int k = (int)(wid - first);
     l_run += __shfl_xor(l_run, 16, 64);
@@ -875,6 +964,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     if (lane == 0) meta[b * hkv + h] = (int)((seg0 + nb - 1) / per) - first + 1;   // #partials of (b, h)
     prefetched = has_next;
     g += run;
+    b = b2; nb = nb2; h = h2; t0 = 0;
   }
 }
 
@@ -883,7 +973,7 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
                                                                      const int* __restrict__ meta,
                                                                      const int32_t* __restrict__ ctx,
                                                                      bf16_t* __restrict__ out, int hq, int hkv,
-                                                                     int slots) {
+                                                                     int slots, float* __restrict__ lse) {
   // out[b, head, :] = sum_k 2^(m_k - M) O_k / sum_k 2^(m_k - M) l_k over the (b, h) segment's split partials;
   // zero rows when the sequence is padding. The kernel is pure latency (a few KB per block), so everything a
   // typical segment needs — the count, and the first kSpec (m, l, O) slots — is loaded SPECULATIVELY in one
@@ -926,20 +1016,38 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
     den += f * ml[c * 2 + 1];
   }
   out[row * 128 + d] = (bf16_t)(cnt > 0 ? num / den : 0.f);
+  // optional log-sum-exp of the scaled scores (natural log; what flash-attn returns as softmax_lse): the scores are
+  // kept in the log2 domain here, so LSE = ln 2 * (M + log2 den); -inf for padded rows
+  if (lse != nullptr && d == 0) lse[row] = cnt > 0 ? 0.6931471805599453f * (M + log2f(den)) : -INFINITY;
 }
 
 inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 2; }
 
+// LDS and grid of decode_mfma8_kernel — shared by its launcher and by nvl_decode_plan, whose per-wave records are only
+// valid for the grid they were made for. `prefix_batch`: sequences whose tile prefix the kernel keeps in LDS (0 with a plan).
+inline size_t mfma8_lds_bytes(int64_t prefix_batch) {
+  return (size_t)kWaves * kMWaveLds + kWaves * sizeof(int) + (size_t)(prefix_batch + 1) * sizeof(int);
+}
+inline int64_t mfma8_grid(int64_t batch, int hkv, int64_t max_context, bool planned) {
+  const size_t lds = mfma8_lds_bytes(planned ? 0 : batch);
+  int64_t grid = (int64_t)nvl_device_cu_count() * (2 * lds <= 160 * 1024 ? 2 : 1);
+  const int64_t max_tiles = batch * hkv * ((max_context + kTile - 1) / kTile);
+  const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
+  if (grid > max_wg) grid = max_wg;
+  return grid < 1 ? 1 : grid;
+}
+
 template <bool FUSED, bool KV8, int G = 8>
 int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                         void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
-                        void* workspace, hipStream_t s, const FusedArgs& fa) {
+                        void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse) {
   const int hq = hkv * G;
   const int slots = stream_slots(max_context);
   float* part_o = (float*)workspace;
   float* part_ml = part_o + (size_t)batch * hq * slots * 128;
   int* meta = (int*)(part_ml + (size_t)batch * hq * slots * 2);
-  const size_t lds = (size_t)kWaves * kMWaveLds + kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
+  // with a per-step plan the kernel keeps no tile prefix in LDS
+  const size_t lds = mfma8_lds_bytes(plan ? 0 : batch);
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set) {
@@ -951,24 +1059,20 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
     attr_set = true;
   }
   NVL_REQUIRE(lds <= 160 * 1024, "nvl_paged_attn_decode: batch=%lld needs %zu B of LDS (> 160 KiB)", (long long)batch, lds);
-  const int cus = nvl_device_cu_count();
-  int64_t grid = (int64_t)cus * (2 * lds <= 160 * 1024 ? 2 : 1);
-  const int64_t max_tiles = batch * hkv * ((max_context + kTile - 1) / kTile);
-  const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
-  if (grid > max_wg) grid = max_wg;
-  if (grid < 1) grid = 1;
+  const int64_t grid = mfma8_grid(batch, hkv, max_context, plan != nullptr);
   hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
                      (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
-                     block_size, slots, scale * 1.4426950408889634f, fa);
+                     block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
-                     meta, ctx, (bf16_t*)out, hq, hkv, slots);
+                     meta, ctx, (bf16_t*)out, hq, hkv, slots, lse);
   return nvl_check_launch("nvl_paged_attn_decode");
 }
 
 template <int G, bool FUSED>
 int launch_decode_stream_fp8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride,
                              const int32_t* ctx, void* out, int64_t batch, int hkv, int block_size,
-                             int64_t max_context, float scale, void* workspace, hipStream_t s, const FusedArgs& fa) {
+                             int64_t max_context, float scale, void* workspace, hipStream_t s, const FusedArgs& fa,
+                             const void* /*plan: only the matrix-core kernel consumes one*/, float* lse) {
   const int hq = hkv * G;
   const int slots = stream_slots(max_context);
   float* part_o = (float*)workspace;
@@ -984,14 +1088,15 @@ int launch_decode_stream_fp8(const void* q, void* kc, void* vc, const int32_t* b
                      (unsigned char*)kc, (unsigned char*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (int)batch, hkv,
                      block_size, slots, scale * 1.4426950408889634f, fa);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
-                     meta, ctx, (bf16_t*)out, hq, hkv, slots);
+                     meta, ctx, (bf16_t*)out, hq, hkv, slots, lse);
   return nvl_check_launch("nvl_paged_attn_decode");
 }
 
 template <int G, bool FUSED>
 int launch_decode_stream(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride,
                          const int32_t* ctx, void* out, int64_t batch, int hkv, int block_size, int64_t max_context,
-                         float scale, void* workspace, hipStream_t s, const FusedArgs& fa) {
+                         float scale, void* workspace, hipStream_t s, const FusedArgs& fa, const void* /*plan*/,
+                         float* lse) {
   const int hq = hkv * G;
   const int slots = stream_slots(max_context);
   float* part_o = (float*)workspace;
@@ -1018,7 +1123,7 @@ int launch_decode_stream(const void* q, void* kc, void* vc, const int32_t* bt, i
                      (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (int)batch, hkv,
                      block_size, slots, scale * 1.4426950408889634f, fa);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
-                     meta, ctx, (bf16_t*)out, hq, hkv, slots);
+                     meta, ctx, (bf16_t*)out, hq, hkv, slots, lse);
   return nvl_check_launch("nvl_paged_attn_decode");
 }
 
@@ -1055,7 +1160,8 @@ bool use_valu_g8() {
 int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* block_tables, int64_t bt_stride,
                   const int32_t* context_lens, void* out, int64_t batch, int num_q_heads, int num_kv_heads,
                   int block_size, int64_t num_blocks, int64_t max_context, float softmax_scale, void* workspace,
-                  size_t workspace_bytes, void* stream, const FusedArgs* fa, const char* who, int kv_dtype) {
+                  size_t workspace_bytes, void* stream, const FusedArgs* fa, const char* who, int kv_dtype,
+                  const void* plan, float* lse) {
   NVL_REQUIRE(q && k_cache && v_cache && block_tables && context_lens && out && workspace, "%s: null pointer", who);
   NVL_REQUIRE(kv_dtype == NVL_KV_BF16 || kv_dtype == NVL_KV_FP8, "%s: kv_dtype=%d (0 bf16, 1 fp8 e4m3)", who, kv_dtype);
   NVL_REQUIRE(batch >= 0 && batch <= 32768, "%s: batch=%lld out of range [0, 32768]", who, (long long)batch);
@@ -1065,6 +1171,7 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
   NVL_REQUIRE(bt_stride * (int64_t)block_size >= max_context, "%s: block table (stride %lld) narrower than max_context=%lld", who, (long long)bt_stride, (long long)max_context);
   NVL_REQUIRE(((uintptr_t)q | (uintptr_t)k_cache | (uintptr_t)v_cache | (uintptr_t)out | (uintptr_t)workspace) % 16 == 0,
               "%s: pointers must be 16-byte aligned", who);
+  NVL_REQUIRE(((uintptr_t)plan % 16 == 0) && ((uintptr_t)lse % 4 == 0), "%s: plan must be 16-byte, lse 4-byte aligned", who);
   if (batch == 0) return NVL_OK;
   const int G = num_q_heads / num_kv_heads;
   const size_t need = nvl_paged_attn_decode_workspace_bytes(batch, num_q_heads, max_context);
@@ -1076,19 +1183,19 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
   case GG:                                                                                                             \
     return fa ? launch_decode_stream_fp8<GG, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,   \
                                                    batch, num_kv_heads, block_size, max_context, softmax_scale,       \
-                                                   workspace, s, *fa)                                                 \
+                                                   workspace, s, *fa, plan, lse)                                                 \
               : launch_decode_stream_fp8<GG, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,      \
-                                                    workspace, s, none);
+                                                    workspace, s, none, plan, lse);
     if (use_mfma_small_g() && (G == 2 || G == 4)) {
 #define NVL_MFMA8_G(GG)                                                                                               \
   if (G == GG)                                                                                                        \
     return fa ? launch_decode_mfma8<true, true, GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,      \
-                                                    workspace, s, *fa)                                                \
+                                                    workspace, s, *fa, plan, lse)                                                \
               : launch_decode_mfma8<false, true, GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, \
                                                      batch, num_kv_heads, block_size, max_context, softmax_scale,     \
-                                                     workspace, s, none);
+                                                     workspace, s, none, plan, lse);
       NVL_MFMA8_G(2)
       NVL_MFMA8_G(4)
 #undef NVL_MFMA8_G
@@ -1100,10 +1207,10 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
       case 8:   // matrix-core variant: fp8 tiles are converted to bf16 on their way into LDS
         return fa ? launch_decode_mfma8<true, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,
-                                                    workspace, s, *fa)
+                                                    workspace, s, *fa, plan, lse)
                   : launch_decode_mfma8<false, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
                                                      batch, num_kv_heads, block_size, max_context, softmax_scale,
-                                                     workspace, s, none);
+                                                     workspace, s, none, plan, lse);
       default:
         nvl_set_error("%s: unsupported group size Hq/Hkv=%d (supported 1,2,4,8)", who, G);
         return NVL_EUNSUPPORTED;
@@ -1114,19 +1221,19 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
   case GG:                                                                                                         \
     return fa ? launch_decode_stream<GG, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,   \
                                                batch, num_kv_heads, block_size, max_context, softmax_scale,       \
-                                               workspace, s, *fa)                                                 \
+                                               workspace, s, *fa, plan, lse)                                                 \
               : launch_decode_stream<GG, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
                                                 batch, num_kv_heads, block_size, max_context, softmax_scale,      \
-                                                workspace, s, none);
+                                                workspace, s, none, plan, lse);
   if (use_mfma_small_g() && (G == 2 || G == 4)) {
 #define NVL_MFMA_G(GG)                                                                                                \
   if (G == GG)                                                                                                        \
     return fa ? launch_decode_mfma8<true, false, GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, \
                                                      batch, num_kv_heads, block_size, max_context, softmax_scale,     \
-                                                     workspace, s, *fa)                                               \
+                                                     workspace, s, *fa, plan, lse)                                               \
               : launch_decode_mfma8<false, false, GG>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,\
                                                       batch, num_kv_heads, block_size, max_context, softmax_scale,    \
-                                                      workspace, s, none);
+                                                      workspace, s, none, plan, lse);
     NVL_MFMA_G(2)
     NVL_MFMA_G(4)
 #undef NVL_MFMA_G
@@ -1139,14 +1246,14 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
       if (!use_valu_g8())
         return fa ? launch_decode_mfma8<true, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
                                                      batch, num_kv_heads, block_size, max_context, softmax_scale,
-                                                     workspace, s, *fa)
+                                                     workspace, s, *fa, plan, lse)
                   : launch_decode_mfma8<false, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
                                                       batch, num_kv_heads, block_size, max_context, softmax_scale,
-                                                      workspace, s, none);
+                                                      workspace, s, none, plan, lse);
       return fa ? launch_decode_stream<8, true>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
-                                                num_kv_heads, block_size, max_context, softmax_scale, workspace, s, *fa)
+                                                num_kv_heads, block_size, max_context, softmax_scale, workspace, s, *fa, plan, lse)
                 : launch_decode_stream<8, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
-                                                 num_kv_heads, block_size, max_context, softmax_scale, workspace, s, none);
+                                                 num_kv_heads, block_size, max_context, softmax_scale, workspace, s, none, plan, lse);
     default:
       nvl_set_error("%s: unsupported group size Hq/Hkv=%d (supported 1,2,4,8)", who, G);
       return NVL_EUNSUPPORTED;
@@ -1160,10 +1267,12 @@ extern "C" int nvl_paged_attn_decode(const void* q, const void* k_cache, const v
                                      const int32_t* block_tables, int64_t bt_stride, const int32_t* context_lens,
                                      void* out, int64_t batch, int num_q_heads, int num_kv_heads, int block_size,
                                      int64_t num_blocks, int64_t max_context, float softmax_scale, void* workspace,
-                                     size_t workspace_bytes, int kv_dtype, void* stream) {
+                                     size_t workspace_bytes, int kv_dtype, const void* plan, float* lse,
+                                     void* stream) {
   return decode_common(q, const_cast<void*>(k_cache), const_cast<void*>(v_cache), block_tables, bt_stride,
                        context_lens, out, batch, num_q_heads, num_kv_heads, block_size, num_blocks, max_context,
-                       softmax_scale, workspace, workspace_bytes, stream, nullptr, "nvl_paged_attn_decode", kv_dtype);
+                       softmax_scale, workspace, workspace_bytes, stream, nullptr, "nvl_paged_attn_decode", kv_dtype,
+                       plan, lse);
 }
 
 extern "C" int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stride, const void* q_norm_w,
@@ -1172,7 +1281,8 @@ extern "C" int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stri
                                            int64_t bt_stride, const int32_t* context_lens, void* out, int64_t batch,
                                            int num_q_heads, int num_kv_heads, int block_size, int64_t num_blocks,
                                            int64_t max_context, float softmax_scale, void* workspace,
-                                           size_t workspace_bytes, int kv_dtype, void* stream) {
+                                           size_t workspace_bytes, int kv_dtype, const void* plan, float* lse,
+                                           void* stream) {
   const char* who = "nvl_paged_attn_decode_fused";
   NVL_REQUIRE(cos_sin && max_pos > 0, "%s: rope table required", who);
   NVL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "%s: q/k norm weights must both be set or both NULL", who);
@@ -1187,5 +1297,38 @@ extern "C" int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stri
   fa.eps = eps;
   return decode_common(qkv, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch, num_q_heads,
                        num_kv_heads, block_size, num_blocks, max_context, softmax_scale, workspace, workspace_bytes,
-                       stream, &fa, who, kv_dtype);
+                       stream, &fa, who, kv_dtype, plan, lse);
+}
+
+// ---- per-step plan ------------------------------------------------------------------------------------------------
+extern "C" size_t nvl_decode_plan_bytes(void) {
+  // header + one record per wave of the largest grid the matrix-core kernel launches (2 workgroups per CU)
+  return sizeof(PlanHeader) + (size_t)nvl_device_cu_count() * 2 * kWaves * sizeof(PlanEntry);
+}
+
+extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int num_q_heads, int num_kv_heads,
+                               int64_t max_context, void* plan, size_t plan_bytes, void* stream) {
+  const char* who = "nvl_decode_plan";
+  NVL_REQUIRE(context_lens && plan, "%s: null pointer", who);
+  NVL_REQUIRE((uintptr_t)plan % 16 == 0, "%s: plan must be 16-byte aligned", who);
+  NVL_REQUIRE(batch >= 0 && batch <= 32768, "%s: batch=%lld out of range [0, 32768]", who, (long long)batch);
+  NVL_REQUIRE(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "%s: Hq=%d not a multiple of Hkv=%d", who, num_q_heads, num_kv_heads);
+  NVL_REQUIRE(max_context > 0, "%s: bad max_context", who);
+  NVL_REQUIRE(plan_bytes >= nvl_decode_plan_bytes(), "%s: plan buffer %zu B < required %zu B", who, plan_bytes, nvl_decode_plan_bytes());
+  if (batch == 0) return NVL_OK;
+  const int nwaves = (int)mfma8_grid(batch, num_kv_heads, max_context, true) * kWaves;
+  const size_t lds = kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
+  static bool attr_done[NVL_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[nvl_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_plan_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess) {
+      nvl_set_error("%s: cannot reserve LDS", who);
+      return NVL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, context_lens, (int)batch,
+                     num_kv_heads, nwaves, (PlanHeader*)plan);
+  return nvl_check_launch(who);
 }

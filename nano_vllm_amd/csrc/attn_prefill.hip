@@ -53,7 +53,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_tok_stride,
     int64_t v_tok_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int num_seqs, int hq,
-    int hkv, int block_size, float scale_log2e, int xcd_map) {
+    int hkv, int block_size, float scale_log2e, int xcd_map, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // two {K: 64 x 256 B, V: 64 x 320 B} tile buffers, then the tile-lookup scratch
   constexpr int NT = NW * 64;                            // threads per workgroup
@@ -350,6 +350,9 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   // ---- epilogue: normalise and store O[query][d] ------------------------------------------------
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
+  // optional log-sum-exp of the scaled scores per (query, head), natural log (flash-attn's softmax_lse): the running
+  // max / sum live in the log2 domain here
+  if (lse != nullptr && q_valid && hi == 0) lse[(int64_t)(q0 + qi) * hq + head] = 0.6931471805599453f * (m_run + log2f(l_tot));
   if (q_valid) {
     bf16_t* op = out + ((int64_t)(q0 + qi) * hq + head) * 128;
 #pragma unroll
@@ -372,7 +375,7 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
                                        const int32_t* cu_seqlens_k, const int32_t* block_tables, int64_t bt_stride,
                                        void* out, int64_t total_q, int num_seqs, int max_seqlen_q, int num_q_heads,
                                        int num_kv_heads, int block_size, int64_t num_blocks, float softmax_scale,
-                                       int kv_dtype, void* stream) {
+                                       int kv_dtype, float* lse, void* stream) {
   NVL_REQUIRE(q && k && v && cu_seqlens_q && cu_seqlens_k && out, "nvl_attn_prefill_varlen: null pointer");
   NVL_REQUIRE(kv_dtype == NVL_KV_BF16 || (kv_dtype == NVL_KV_FP8 && block_tables != nullptr),
               "nvl_attn_prefill_varlen: kv_dtype=%d (0 bf16; 1 fp8 e4m3 only with a paged cache)", kv_dtype);
@@ -443,7 +446,7 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
 #define NVL_PF_LAUNCH(P, K8, NWV)                                                                                      \
   hipLaunchKernelGGL((prefill_attn_kernel<P, K8, NWV>), grid, dim3(NWV * 64), lds, s, (const bf16_t*)q,                 \
                      (const bf16_t*)k, (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k,        \
-                     block_tables, bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map)
+                     block_tables, bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map, lse)
   if (paged && kv_dtype == NVL_KV_FP8) {
     if (eight) NVL_PF_LAUNCH(true, true, 8); else NVL_PF_LAUNCH(true, true, 4);
   } else if (paged) {

@@ -399,6 +399,12 @@ class ModelRunner:
         # zeroed once: the kernel's arrival counters live in it and are left at zero by every launch
         self.decode_ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
         self.decode_ws_b = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
+        # per-step work plan of the decode attention launches (ops.decode_plan): made once per step by the first
+        # node of the decode graph, read by every layer's attention launch. NVL_DECODE_PLAN=0: every launch derives
+        # its own schedule again (A/B measurements)
+        self.use_plan = os.environ.get("NVL_DECODE_PLAN", "1") != "0"
+        self.decode_plan = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
+        self.decode_plan_b = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
         self._step_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     # ------------------------------------------------------------------ warm-up + KV cache
@@ -561,11 +567,14 @@ class ModelRunner:
             logits = self.model.compute_logits_shard(hidden)
             sampler.forward_shard(logits, temps, col0, out, offset_dev=rng)
 
-    def _decode_rows(self, r0: int, r1: int, ws, sampler):
+    def _decode_rows(self, r0: int, r1: int, ws, sampler, plan=None):
         """Decode forward for rows [r0, r1) of the static device buffers, on the current stream."""
         t = self.dstage.t
+        if plan is not None:
+            ops.decode_plan(t["ctx"][r0:r1], self.geo["heads"], self.geo["kv_heads"], self.config.max_model_len, plan)
         set_context(False, slot_mapping=t["slots"][r0:r1], context_lens=t["ctx"][r0:r1],
-                    block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len)
+                    block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len,
+                    decode_plan=plan)
         hidden = self.model(t["ids"][r0:r1], t["pos"][r0:r1])
         self._sample(hidden, t["temps"][r0:r1], self.tokens_dev[r0:r1], t["rng"][:1], sampler)
         reset_context()
@@ -593,11 +602,11 @@ class ModelRunner:
             side = self.side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._decode_rows(h, bs, self.decode_ws_b, self.sampler_b)
-            self._decode_rows(0, h, self.decode_ws, self.sampler)
+                self._decode_rows(h, bs, self.decode_ws_b, self.sampler_b, self.decode_plan_b if self.use_plan else None)
+            self._decode_rows(0, h, self.decode_ws, self.sampler, self.decode_plan if self.use_plan else None)
             main.wait_stream(side)
         else:
-            self._decode_rows(0, bs, self.decode_ws, self.sampler)
+            self._decode_rows(0, bs, self.decode_ws, self.sampler, self.decode_plan if self.use_plan else None)
 
     @torch.inference_mode()
     def _launch_decode(self, n: int) -> None:

@@ -144,7 +144,8 @@ class Attention(nn.Module):
                 ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(n, hq, max_context), dtype=torch.uint8,
                                  device=qkv.device)
             return ops.paged_attn_decode_fused(qkv, q_norm_w, k_norm_w, eps, rope_table, self.k_cache, self.v_cache,
-                                               ctx.block_tables, ctx.context_lens, hq, self.scale, max_context, ws)
+                                               ctx.block_tables, ctx.context_lens, hq, self.scale, max_context, ws,
+                                               plan=ctx.decode_plan)
         q = torch.empty((n, hq, 128), dtype=qkv.dtype, device=qkv.device)
         need_k = ctx.is_prefill and ctx.block_tables is None      # non-paged prefill reads packed K
         k = torch.empty((n, hkv, 128), dtype=qkv.dtype, device=qkv.device) if need_k else None
@@ -166,7 +167,7 @@ class Attention(nn.Module):
             ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(q.shape[0], self.num_heads, max_context),
                              dtype=torch.uint8, device=q.device)
         return ops.paged_attn_decode(q, self.k_cache, self.v_cache, ctx.block_tables, ctx.context_lens, self.scale,
-                                     max_context, ws)
+                                     max_context, ws, plan=ctx.decode_plan)
 
 
 class Sampler(nn.Module):

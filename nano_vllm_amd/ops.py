@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnvl_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 # name -> (restype, argtypes); mirrors include/nvl.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -41,13 +41,17 @@ SIGNATURES = {
                                         c_int64, c_int, c_void_p]),
     "nvl_paged_attn_decode_workspace_bytes": (c_size_t, [c_int64, c_int, c_int64]),
     "nvl_paged_attn_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
-                                      c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int, c_void_p]),
+                                      c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int,
+                                      c_void_p, c_void_p, c_void_p]),
+    "nvl_decode_plan_bytes": (c_size_t, []),
+    "nvl_decode_plan": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_size_t, c_void_p]),
     "nvl_paged_attn_decode_fused": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p,
                                             c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
-                                            c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int, c_void_p]),
+                                            c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int, c_void_p,
+                                            c_void_p, c_void_p]),
     "nvl_attn_prefill_varlen": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                         c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
-                                        c_int, c_void_p]),
+                                        c_int, c_void_p, c_void_p]),
     "nvl_sample_workspace_bytes": (c_size_t, [c_int64]),
     "nvl_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_void_p,
                            c_void_p, c_size_t, c_void_p]),
@@ -317,10 +321,36 @@ def paged_attn_decode_workspace_bytes(max_batch: int, num_q_heads: int, max_cont
     return lib().nvl_paged_attn_decode_workspace_bytes(max_batch, num_q_heads, max_context)
 
 
+def decode_plan_bytes() -> int:
+    return lib().nvl_decode_plan_bytes()
+
+
+def decode_plan(context_lens: torch.Tensor, num_q_heads: int, num_kv_heads: int, max_context: int,
+                plan: torch.Tensor | None = None) -> torch.Tensor:
+    """Per-step work plan of the decode attention launches (same for every layer of the step): `plan` is a uint8
+    device buffer of decode_plan_bytes() bytes, allocated when None."""
+    _dev(context_lens, "context_lens")
+    assert context_lens.dtype == torch.int32 and context_lens.is_contiguous()
+    if plan is None:
+        plan = torch.empty(decode_plan_bytes(), dtype=torch.uint8, device=context_lens.device)
+    _check(lib().nvl_decode_plan(context_lens.data_ptr(), context_lens.numel(), num_q_heads, num_kv_heads, max_context,
+                                 plan.data_ptr(), plan.numel(), _stream()))
+    return plan
+
+
+def _lse_ptr(lse: torch.Tensor | None, shape: tuple) -> int | None:
+    if lse is None:
+        return None
+    assert lse.dtype == torch.float32 and lse.is_contiguous() and tuple(lse.shape) == shape, (lse.shape, shape)
+    return lse.data_ptr()
+
+
 def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
                       context_lens: torch.Tensor, scale: float, max_context: int, workspace: torch.Tensor,
-                      out: torch.Tensor | None = None) -> torch.Tensor:
-    """q: [B, Hq, 128]; caches [num_blocks, Hkv, block_size, 128]; block_tables int32 [B, W]."""
+                      out: torch.Tensor | None = None, plan: torch.Tensor | None = None,
+                      lse: torch.Tensor | None = None) -> torch.Tensor:
+    """q: [B, Hq, 128]; caches [num_blocks, Hkv, block_size, 128]; block_tables int32 [B, W]. `plan`: decode_plan()
+    of this step; `lse`: optional fp32 [B, Hq] output (log-sum-exp of the scaled scores)."""
     _dev(q, "q")
     b, hq, d = q.shape
     assert d == 128 and q.is_contiguous() and block_tables.dtype == torch.int32 and context_lens.dtype == torch.int32
@@ -331,14 +361,16 @@ def paged_attn_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Ten
                                        block_tables.stride(0), context_lens.data_ptr(), out.data_ptr(), b, hq,
                                        k_cache.shape[1], k_cache.shape[2], k_cache.shape[0], max_context, scale,
                                        workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-                                       kv_dtype_of(k_cache), _stream()))
+                                       kv_dtype_of(k_cache), plan.data_ptr() if plan is not None else None,
+                                       _lse_ptr(lse, (b, hq)), _stream()))
     return out
 
 
 def paged_attn_decode_fused(qkv: torch.Tensor, q_norm_w, k_norm_w, eps: float, cos_sin: torch.Tensor,
                             k_cache: torch.Tensor, v_cache: torch.Tensor, block_tables: torch.Tensor,
                             context_lens: torch.Tensor, num_q_heads: int, scale: float, max_context: int,
-                            workspace: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+                            workspace: torch.Tensor, out: torch.Tensor | None = None,
+                            plan: torch.Tensor | None = None, lse: torch.Tensor | None = None) -> torch.Tensor:
     """Decode step in one launch: q/k-norm + RoPE (position = context_len - 1) + KV-cache store of the
     new token + paged attention. qkv: raw qkv GEMM output [B, (Hq + 2*Hkv)*128]."""
     _dev(qkv, "qkv")
@@ -354,16 +386,16 @@ def paged_attn_decode_fused(qkv: torch.Tensor, q_norm_w, k_norm_w, eps: float, c
         k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(), block_tables.stride(0),
         context_lens.data_ptr(), out.data_ptr(), b, num_q_heads, k_cache.shape[1], k_cache.shape[2], k_cache.shape[0],
         max_context, scale, workspace.data_ptr(), workspace.numel() * workspace.element_size(), kv_dtype_of(k_cache),
-        _stream()))
+        plan.data_ptr() if plan is not None else None, _lse_ptr(lse, (b, num_q_heads)), _stream()))
     return out
 
 
 def attn_prefill_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor,
                         cu_seqlens_k: torch.Tensor, max_seqlen_q: int, scale: float,
                         block_tables: torch.Tensor | None = None, num_kv_heads: int | None = None,
-                        out: torch.Tensor | None = None) -> torch.Tensor:
+                        out: torch.Tensor | None = None, lse: torch.Tensor | None = None) -> torch.Tensor:
     """q: [Nq, Hq, 128]. block_tables None: k, v packed [Nk, Hkv, 128] (token-strided views ok);
-    otherwise k, v are the paged caches [num_blocks, Hkv, block_size, 128]."""
+    otherwise k, v are the paged caches [num_blocks, Hkv, block_size, 128]. `lse`: optional fp32 [Nq, Hq] output."""
     _dev(q, "q")
     nq, hq, d = q.shape
     assert d == 128 and q.is_contiguous()
@@ -377,14 +409,14 @@ def attn_prefill_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_se
         _check(lib().nvl_attn_prefill_varlen(q.data_ptr(), k.data_ptr(), v.data_ptr(), k.stride(0), v.stride(0),
                                              cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(), None, 0,
                                              out.data_ptr(), nq, num_seqs, max_seqlen_q, hq, hkv, 0, 0, scale,
-                                             KV_BF16, _stream()))
+                                             KV_BF16, _lse_ptr(lse, (nq, hq)), _stream()))
     else:
         assert block_tables.dtype == torch.int32 and block_tables.stride(1) == 1
         _check(lib().nvl_attn_prefill_varlen(q.data_ptr(), k.data_ptr(), v.data_ptr(), 0, 0,
                                              cu_seqlens_q.data_ptr(), cu_seqlens_k.data_ptr(),
                                              block_tables.data_ptr(), block_tables.stride(0), out.data_ptr(), nq,
                                              num_seqs, max_seqlen_q, hq, k.shape[1], k.shape[2], k.shape[0], scale,
-                                             kv_dtype_of(k), _stream()))
+                                             kv_dtype_of(k), _lse_ptr(lse, (nq, hq)), _stream()))
     return out
 
 

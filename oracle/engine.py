@@ -231,6 +231,7 @@ class OracleEngine:
                    input_ids=ids.tolist(), positions=pos.tolist(), slots=meta.slot_mapping.tolist())
         if self.model is not None:
             logits = self.model.compute_logits(self.model.forward(ids, pos, meta), meta)   # model_runner.py:198
+            logits = logits.cpu()                                   # (a device-resident model: judge on the host)
             temps = torch.tensor([s["temp"] for s in batch], dtype=torch.float32)
             greedy = ops.greedy(logits)
             if bool((temps > 0).any()):

@@ -30,12 +30,18 @@ class Meta:
 
 class OracleQwen3:
 
-    def __init__(self, cfg: dict, weights: dict[str, torch.Tensor], compiled: bool = True):
+    def __init__(self, cfg: dict, weights: dict[str, torch.Tensor], compiled: bool = True, device=None):
+        """`device`: where the restatement's torch ops run. None / "cpu" is the oracle proper; a HIP device runs the
+        SAME Python on torch's own kernels (hipBLASLt GEMMs, fp32 accumulate) — used by the GPU tests for workloads the
+        CPU cannot finish in minutes (tests/test_e2e_gpu.py checks it against the CPU run first). Step metadata
+        (cu_seqlens, context lengths, block tables) stays on the host; only bulk data lives on the device."""
+        self.dev = torch.device(device) if device is not None else torch.device("cpu")
+        weights = {k: v.to(self.dev) for k, v in weights.items()}
         self.cfg, self.w, self.compiled = cfg, weights, compiled
         self.h, self.hkv, self.d = cfg["num_attention_heads"], cfg["num_key_value_heads"], cfg["head_dim"]
         self.eps = cfg["rms_norm_eps"]
         self.L = cfg["num_hidden_layers"]
-        self.table = ops.rope_table(self.d, cfg["max_position_embeddings"], cfg["rope_theta"])
+        self.table = ops.rope_table(self.d, cfg["max_position_embeddings"], cfg["rope_theta"]).to(self.dev)
         self.k_cache: list[torch.Tensor] = []
         self.v_cache: list[torch.Tensor] = []
         # fused projections exactly as the loader packs them (qwen3.py:187-193, linear.py:114-128)
@@ -51,13 +57,13 @@ class OracleQwen3:
         # dtype follows the weights: bf16 as the reference (hf_config.torch_dtype); an fp32 weight dict gives the
         # "exact arithmetic" variant used as the yardstick of the logits-error test (no intermediate rounding)
         dt = self.lm_head.dtype
-        self.k_cache = [torch.zeros(shape, dtype=dt) for _ in range(self.L)]
-        self.v_cache = [torch.zeros(shape, dtype=dt) for _ in range(self.L)]
+        self.k_cache = [torch.zeros(shape, dtype=dt, device=self.dev) for _ in range(self.L)]
+        self.v_cache = [torch.zeros(shape, dtype=dt, device=self.dev) for _ in range(self.L)]
 
     # -- layers/attention.py:59-75 ---------------------------------------------------------------
     def _attention(self, layer: int, q, k, v, meta: Meta):
         if self.k_cache:
-            ops.store_kvcache(k, v, self.k_cache[layer], self.v_cache[layer], meta.slot_mapping)      # :63
+            ops.store_kvcache(k, v, self.k_cache[layer], self.v_cache[layer], meta.slot_mapping.to(self.dev))   # :63
         scale = self.d ** -0.5                                                                       # qwen3.py:39
         if meta.is_prefill:
             if meta.block_tables is not None:                                                        # :65-66
@@ -71,6 +77,7 @@ class OracleQwen3:
     def forward(self, input_ids: torch.Tensor, positions: torch.Tensor, meta: Meta) -> torch.Tensor:
         """Qwen3Model.forward (qwen3.py:173-183) -> hidden states [N, hidden]."""
         w, c = self.w, self.compiled
+        input_ids, positions = input_ids.to(self.dev), positions.to(self.dev)
         hidden = F.embedding(input_ids, w["model.embed_tokens.weight"])                              # :178
         residual = None
         for i in range(self.L):
@@ -100,7 +107,7 @@ class OracleQwen3:
     def compute_logits(self, hidden: torch.Tensor, meta: Meta) -> torch.Tensor:
         """ParallelLMHead.forward at tp=1 (embed_head.py:56-61)."""
         if meta.is_prefill:
-            last = (meta.cu_seqlens_q[1:] - 1).long()
+            last = (meta.cu_seqlens_q[1:] - 1).long().to(hidden.device)
             hidden = hidden[last].contiguous()
         return F.linear(hidden, self.lm_head)
 

@@ -111,8 +111,10 @@ def from_head_major(cache: torch.Tensor) -> torch.Tensor:
 # flash-attn entry points used at layers/attention.py:67-74 (package absent: restated from its
 # documented semantics — fp32 scores/softmax, P cast to the input dtype before P.V, fp32
 # accumulate, causal mask aligned to the bottom-right corner, GQA by head // (Hq/Hkv)).
-def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, causal_offset: int | None):
-    """q [Lq,Hq,D], k/v [Lk,Hkv,D] -> [Lq,Hq,D]. causal_offset = Lk - Lq (None: no mask)."""
+def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, causal_offset: int | None,
+            return_lse: bool = False):
+    """q [Lq,Hq,D], k/v [Lk,Hkv,D] -> [Lq,Hq,D]. causal_offset = Lk - Lq (None: no mask).
+    return_lse: also the fp32 log-sum-exp of the scaled scores [Lq, Hq] (flash-attn's softmax_lse)."""
     lq, hq, d = q.shape
     lk, hkv, _ = k.shape
     g = hq // hkv
@@ -128,7 +130,10 @@ def _attend(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, scale: float, cau
     e = torch.exp(s - m)
     l = e.sum(dim=-1, keepdim=True)
     o = torch.matmul(e.to(q.dtype).float(), v32) / l              # P rounded to bf16 before P.V
-    return o.permute(1, 0, 2).to(q.dtype)
+    o = o.permute(1, 0, 2).to(q.dtype)
+    if return_lse:
+        return o, (m + torch.log(l)).squeeze(-1).transpose(0, 1).contiguous()
+    return o
 
 
 def _gather_paged(cache: torch.Tensor, table_row: torch.Tensor, length: int) -> torch.Tensor:
@@ -140,10 +145,12 @@ def _gather_paged(cache: torch.Tensor, table_row: torch.Tensor, length: int) -> 
 
 
 def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu_seqlens_k,
-                           softmax_scale, causal=True, block_table=None):
+                           softmax_scale, causal=True, block_table=None, return_softmax_lse=False):
     """Varlen attention as called at layers/attention.py:67-70. With block_table, k/v are the
-    paged caches (reference layout) and sequence s reads keys cache[block_table[s, t//B], t%B]."""
+    paged caches (reference layout) and sequence s reads keys cache[block_table[s, t//B], t%B].
+    return_softmax_lse (flash-attn's option of the same name): also fp32 [sum Lq, Hq] log-sum-exp."""
     out = torch.empty_like(q)
+    lse = torch.full(q.shape[:2], float("-inf"), dtype=torch.float32, device=q.device)
     ns = cu_seqlens_q.numel() - 1
     for s in range(ns):
         q0, q1 = int(cu_seqlens_q[s]), int(cu_seqlens_q[s + 1])
@@ -156,22 +163,24 @@ def flash_attn_varlen_func(q, k, v, max_seqlen_q, cu_seqlens_q, max_seqlen_k, cu
             ks = _gather_paged(k, block_table[s], k1 - k0)
             vs = _gather_paged(v, block_table[s], k1 - k0)
         off = (k1 - k0) - (q1 - q0) if causal else None
-        out[q0:q1] = _attend(q[q0:q1], ks, vs, softmax_scale, off)
-    return out
+        out[q0:q1], lse[q0:q1] = _attend(q[q0:q1], ks, vs, softmax_scale, off, True)
+    return (out, lse) if return_softmax_lse else out
 
 
-def flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, causal=True):
+def flash_attn_with_kvcache(q, k_cache, v_cache, cache_seqlens, block_table, softmax_scale, causal=True,
+                            return_softmax_lse=False):
     """Single-query paged attention as called at layers/attention.py:72-74. q [B,1,Hq,D] ->
-    [B,1,Hq,D]. Rows with cache_seqlens == 0 (graph padding) return zeros."""
+    [B,1,Hq,D]. Rows with cache_seqlens == 0 (graph padding) return zeros (lse -inf)."""
     out = torch.zeros_like(q)
+    lse = torch.full((q.shape[0], q.shape[2]), float("-inf"), dtype=torch.float32, device=q.device)
     for b in range(q.shape[0]):
         n = int(cache_seqlens[b])
         if n == 0:
             continue
         ks = _gather_paged(k_cache, block_table[b], n)
         vs = _gather_paged(v_cache, block_table[b], n)
-        out[b] = _attend(q[b], ks, vs, softmax_scale, n - 1 if causal else None)
-    return out
+        out[b], lse[b:b + 1] = _attend(q[b], ks, vs, softmax_scale, n - 1 if causal else None, True)
+    return (out, lse) if return_softmax_lse else out
 
 
 # ----------------------------------------------------------------------------------------------

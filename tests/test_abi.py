@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for sym in _declared():
         assert hasattr(lib, sym), f"{sym} declared in include/nvl.h but not exported"
     lib.nvl_abi_version.restype = ctypes.c_int
-    assert lib.nvl_abi_version() == 2
+    assert lib.nvl_abi_version() == 3
 
 
 def test_ctypes_binding_matches_header():
@@ -43,20 +43,23 @@ def test_host_side_argument_validation_without_gpu():
     lib = ops.load_library()
     rc = lib.nvl_rmsnorm(None, 0, None, None, 0, 1, 1, 1024, 1e-6, None)
     assert rc == -1 and b"null pointer" in lib.nvl_last_error()
-    rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 16, 6, 256, 8, 4096, 0.1, 16, 1 << 30, 0, None)
+    rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 16, 6, 256, 8, 4096, 0.1, 16, 1 << 30, 0, None, None, None)
     assert rc == -1 and b"not a multiple" in lib.nvl_last_error()
-    rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8, 4096, 0.1, 16, 1 << 30, 7, None)
+    rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8, 4096, 0.1, 16, 1 << 30, 7, None, None, None)
     assert rc == -1 and b"kv_dtype" in lib.nvl_last_error()
     # group sizes outside 1, 2, 4, 8 are refused (either cache dtype), not emulated
-    rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 48, 16, 256, 16, 4096, 0.1, 16, 1 << 30, 1, None)
+    rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 48, 16, 256, 16, 4096, 0.1, 16, 1 << 30, 1, None, None, None)
     assert rc == -3 and b"group size" in lib.nvl_last_error()
     # fused decode entry: rope table is mandatory; q/k norm weights come as a pair
     rc = lib.nvl_paged_attn_decode_fused(16, 4096, None, None, 1e-6, None, 0, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
-                                         4096, 0.1, 16, 1 << 30, 0, None)
+                                         4096, 0.1, 16, 1 << 30, 0, None, None, None)
     assert rc == -1 and b"rope table" in lib.nvl_last_error()
     rc = lib.nvl_paged_attn_decode_fused(16, 4096, 16, None, 1e-6, 16, 4096, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
-                                         4096, 0.1, 16, 1 << 30, 0, None)
+                                         4096, 0.1, 16, 1 << 30, 0, None, None, None)
     assert rc == -1 and b"both be set or both NULL" in lib.nvl_last_error()
+    # per-step decode plan: buffer size is validated on the host
+    rc = lib.nvl_decode_plan(16, 4, 16, 8, 4096, 16, 8, None)
+    assert rc == -1 and b"plan buffer" in lib.nvl_last_error()
     # skinny linear: shape coverage is a query, an uncovered shape is EUNSUPPORTED (-3), never a silent fallback
     assert lib.nvl_linear_decode_splits(144, 4096, 1024, 0) == 1
     assert lib.nvl_linear_decode_splits(144, 1024, 2048, 2) == 4

@@ -1,13 +1,14 @@
-"""End-to-end parity on the MI355X: our engine (HIP kernels, hipGraph decode) vs the CPU oracle
-engine on the same synthetic checkpoint and prompts.
+"""End-to-end parity on the MI355X: our engine (HIP kernels, hipGraph decode) vs the oracle engine on the same
+synthetic checkpoint and prompts.
 
-Parity definition: greedy (T=0). bf16 noise makes free-running comparison of
-random-weight models meaningless after the first near-tie, so the oracle is TEACHER-FORCED with
-our tokens and every one of our decisions is judged against the oracle's logits for the same
-history: the chosen token must be the oracle's argmax, or lie within `TOL` of the oracle's max
-logit (TOL ~ 2x the measured reference-eager-vs-reference-compiled logits floor); and the large
-majority of steps must be exact argmax matches. Scheduling (batch composition, block tables) must
-be identical step for step.
+Parity definition (implemented in oracle/judge.py): greedy (T = 0). bf16 noise makes a free-running
+comparison of random-weight models meaningless after the first near-tie, so the oracle is TEACHER-FORCED with our
+tokens and every one of our decisions is judged against the oracle's logits for the same history:
+  * the noise FLOOR is measured on the run itself: the same history through the oracle with the reference's eager
+    rounding vs the oracle with its compiled rounding (max|dlogit| / absmax — the reference against itself);
+  * every row whose oracle top-1 / top-2 margin exceeds 2 x floor must be the oracle's argmax EXACTLY;
+  * a sub-margin row (a near-tie below the noise) may differ, but only by a token within 2 x floor of the maximum.
+Scheduling (batch composition, block tables) must be identical step for step.
 """
 import os
 import tempfile
@@ -16,15 +17,17 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
-TOL = 0.15
 
 
-def _run_ours(path, prompts, max_tokens, **kw):
+def _run_ours(path, prompts, max_tokens, capture_logits=False, **kw):
     from nano_vllm_amd import LLM, SamplingParams
     llm = LLM(path, **kw)
     rec = []
     runner = llm.model_runner
     orig = runner.call
+    logits_log = []
+    if capture_logits:
+        runner.sampler.capture = logits_log                # every step's logits, whichever sampling path runs
 
     def snap(seqs, is_prefill):
         return dict(prefill=is_prefill, seq_ids=[s.seq_id for s in seqs], tables=[list(s.block_table) for s in seqs],
@@ -52,38 +55,28 @@ def _run_ours(path, prompts, max_tokens, **kw):
     nblk = llm.config.num_kvcache_blocks
     runner.call = orig
     llm.exit()
+    if capture_logits:
+        assert len(logits_log) == len(rec)
+        for r, lg in zip(rec, logits_log):
+            r["logits"] = lg
     return outs, rec, nblk
 
 
+def _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device=None, **sched_kw):
+    from oracle.judge import judge_run
+    return judge_run(cfg, w, prompts, max_tokens, rec, nblk, device=device, **sched_kw)
+
+
+def _check(name, v, min_rows=1):
+    print(v.line(name) + (f"; logits max|ours - oracle| / absmax {v.worst_logit_err_rel:.5f}" if v.worst_logit_err_rel else ""))
+    assert v.rows >= min_rows
+    assert v.ok(), v.violations[:5]
+
+
 def _judge(path, prompts, max_tokens, rec, nblk, **sched_kw):
-    from oracle.engine import OracleEngine
-    from oracle.model import OracleQwen3, load_weights
+    from oracle.model import load_weights
     cfg, w = load_weights(path)
-    eng = OracleEngine(OracleQwen3(cfg, w, compiled=True), nblk, 256, **sched_kw)
-    eng.keep_logits = True
-    for p, m in zip(prompts, max_tokens):
-        eng.add(p, 0.0, m, True)
-    exact = total = 0
-    worst = 0.0
-    base = None
-    for i, r in enumerate(rec):
-        eng.step(forced_tokens=r["tokens"])
-        o = eng.trace[-1]
-        if base is None:
-            base = r["seq_ids"][0] - o["seq_ids"][0]
-        assert o["is_prefill"] == r["prefill"], f"step {i}: phase differs"
-        assert [s + base for s in o["seq_ids"]] == r["seq_ids"], f"step {i}: batch composition differs"
-        assert o["tables"] == r["tables"], f"step {i}: block tables differ"
-        logits = o["logits"]
-        for row, tok in enumerate(r["tokens"]):
-            if r["prefill"] and o["sched"][row] + o["cached"][row] < 0:
-                continue
-            gap = float(logits[row].max() - logits[row, tok])
-            worst = max(worst, gap)
-            exact += gap == 0.0
-            total += 1
-    assert not eng.waiting and not eng.running
-    return exact, total, worst
+    return _judge_run(cfg, w, prompts, max_tokens, rec, nblk, **sched_kw)
 
 
 @pytest.fixture(scope="module")
@@ -107,9 +100,7 @@ def test_tiny_model_greedy_parity(tiny_ckpt, eager):
     outs, rec, nblk = _run_ours(tiny_ckpt, prompts, max_tokens, enforce_eager=eager, max_model_len=2048,
                                 num_kvcache_blocks=32, max_num_seqs=16)
     assert [len(o["token_ids"]) for o in outs] == max_tokens
-    exact, total, worst = _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, max_num_seqs=16)
-    print(f"tiny eager={eager}: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
-    assert worst <= TOL and exact >= 0.9 * total
+    _check(f"tiny eager={eager}", _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, max_num_seqs=16), sum(max_tokens))
 
 
 @pytest.mark.parametrize("name", ["qwen3-tiny-untied", "qwen3-tiny-g8"])
@@ -124,9 +115,7 @@ def test_other_head_geometries_greedy_parity(name):
     outs, rec, nblk = _run_ours(path, prompts, max_tokens, enforce_eager=False, max_model_len=2048,
                                 num_kvcache_blocks=24, max_num_seqs=8)
     assert [len(o["token_ids"]) for o in outs] == max_tokens
-    exact, total, worst = _judge(path, prompts, max_tokens, rec, nblk, max_num_seqs=8)
-    print(f"{name}: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
-    assert worst <= TOL and exact >= 0.9 * total
+    _check(name, _judge(path, prompts, max_tokens, rec, nblk, max_num_seqs=8), sum(max_tokens))
 
 
 def test_tiny_model_chunked_prefill_and_preemption(tiny_ckpt):
@@ -140,10 +129,8 @@ def test_tiny_model_chunked_prefill_and_preemption(tiny_ckpt):
     outs, rec, nblk = _run_ours(tiny_ckpt, prompts, max_tokens, enforce_eager=True, max_model_len=2048,
                                 num_kvcache_blocks=9, max_num_seqs=8, max_num_batched_tokens=640)
     assert any(r["prefill"] and len(r["seq_ids"]) == 1 for r in rec)
-    exact, total, worst = _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, max_num_seqs=8,
-                                 max_num_batched_tokens=640)
-    print(f"tiny chunked/preempt: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
-    assert worst <= TOL and exact >= 0.9 * total
+    _check("tiny chunked/preempt", _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, max_num_seqs=8,
+                                          max_num_batched_tokens=640), sum(max_tokens))
 
 
 def test_sampling_temperature_runs_and_is_seeded(tiny_ckpt):
@@ -189,47 +176,71 @@ def _oracle_weights_06b(device):
     return cfg, {n: synth_tensor(n, s, 0, device=device).cpu() for n, s in parameter_shapes(cfg).items()}
 
 
-@pytest.mark.parametrize("fused_lm_head", [False, True])
-def test_qwen3_06b_shape_greedy_parity_vs_oracle(ckpt_06b, fused_lm_head, monkeypatch):
-    """(fused_lm_head: the opt-in nvl_lmhead_sample path — sampling inside the lm_head GEMM's epilogue.)
-    Full-size layers (fused decode attention G=2, skinny decode GEMMs at K=1024/2048/3072, sampler
-    over 151,936 logits): every token we pick must be the CPU oracle's argmax (or within TOL) for the
-    same history, with identical scheduling."""
+def test_qwen3_06b_shape_greedy_parity_vs_cpu_oracle_and_device_oracle_agrees(ckpt_06b):
+    """Full-size layers (fused decode attention G = 2, skinny decode GEMMs at K = 1024 / 2048 / 3072, sampler over
+    151,936 logits) judged by the CPU oracle (both roundings, floor measured on the run) under the margin rule.
+    The same history is also run through the SAME oracle code with its tensors on the GPU (torch's own kernels): its
+    logits must agree with the CPU run to within half a floor — that is what licenses the device-resident oracle for
+    the config-2-sized judgement below, which the CPU cannot finish in minutes."""
     from oracle.engine import OracleEngine
     from oracle.model import OracleQwen3
-    import nano_vllm_amd.layers as layers_mod
-    monkeypatch.setattr(layers_mod, "_FUSED_LMHEAD", fused_lm_head)
     prompts = _prompts(3, 20, 300, 10000, seed=21)
-    max_tokens = [24, 22, 26] if not fused_lm_head else [8, 6, 7]
+    max_tokens = [16, 14, 18]
+    outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, enforce_eager=False, max_model_len=1024,
+                                num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True, capture_logits=True)
+    cfg, w = _oracle_weights_06b("cuda")
+    v = _judge_run(cfg, w, prompts, max_tokens, rec, nblk, max_num_seqs=8)
+    _check("0.6B shapes (CPU oracle)", v, sum(max_tokens))
+    engs = [OracleEngine(OracleQwen3(cfg, w, compiled=True, device=d), nblk, 256, max_num_seqs=8) for d in (None, "cuda")]
+    worst = 0.0
+    for eng in engs:
+        eng.keep_logits = True
+        for p_, m in zip(prompts, max_tokens):
+            eng.add(p_, 0.0, m, True)
+    for r in rec[:6]:                                     # the prefill step and five decode steps
+        for eng in engs:
+            eng.step(forced_tokens=r["tokens"])
+        a_, b_ = engs[0].trace[-1]["logits"], engs[1].trace[-1]["logits"]
+        worst = max(worst, float((a_ - b_).abs().max()) / float(a_.abs().max()))
+    print(f"device-resident oracle vs CPU oracle: max|dlogit| / absmax {worst:.5f} (floor of this run {v.floor_rel:.5f})")
+    assert worst <= 0.5 * v.floor_rel
+
+
+def test_qwen3_06b_fused_lm_head_greedy_parity(ckpt_06b, monkeypatch):
+    """The opt-in nvl_lmhead_sample path (sampling inside the lm_head GEMM's epilogue) under the same rule."""
+    import nano_vllm_amd.layers as layers_mod
+    monkeypatch.setattr(layers_mod, "_FUSED_LMHEAD", True)
+    prompts = _prompts(3, 20, 300, 10000, seed=21)
+    max_tokens = [8, 6, 7]
     outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, enforce_eager=False, max_model_len=1024,
                                 num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True)
     cfg, w = _oracle_weights_06b("cuda")
-    eng = OracleEngine(OracleQwen3(cfg, w, compiled=True), nblk, 256, max_num_seqs=8)
-    eng.keep_logits = True
-    for p, m in zip(prompts, max_tokens):
-        eng.add(p, 0.0, m, True)
-    exact = total = 0
-    worst = 0.0
-    for i, r in enumerate(rec):
-        eng.step(forced_tokens=r["tokens"])
-        o = eng.trace[-1]
-        assert o["is_prefill"] == r["prefill"] and o["tables"] == r["tables"], f"step {i}: schedule differs"
-        for row, tok in enumerate(r["tokens"]):
-            gap = float(o["logits"][row].max() - o["logits"][row, tok])
-            worst = max(worst, gap)
-            exact += gap == 0.0
-            total += 1
-    print(f"0.6B shapes: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
-    assert worst <= TOL and exact >= 0.8 * total
+    _check("0.6B shapes, fused lm_head", _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device="cuda",
+                                                     max_num_seqs=8), sum(max_tokens))
+
+
+def test_config2_shaped_batch_greedy_parity_vs_device_oracle(ckpt_06b):
+    """BASELINE.json config 2's regime at Qwen3-0.6B width: 64 sequences with the bench's ragged prompt lengths
+    (100-1024 tokens, ids < 10,000, seeded like the reference bench.py), 33 output tokens each => three 16,384-token
+    prefill batches and 32 hipGraph decode steps at B = 64, ~2,100 judged decisions. Judge: the device-resident oracle
+    (validated against the CPU oracle above), teacher-forced, both roundings, margin rule."""
+    from random import Random
+    rnd = Random(0)
+    prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(100, 1024))] for _ in range(64)]
+    max_tokens = [33] * 64
+    outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, enforce_eager=False, max_model_len=4096,
+                                num_kvcache_blocks=400, max_num_seqs=64, dummy_weights=True)
+    assert sum(1 for r in rec if not r["prefill"] and len(r["tokens"]) == 64) == 32
+    cfg, w = _oracle_weights_06b("cuda")
+    v = _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device="cuda", max_num_seqs=64)
+    _check("config-2-shaped batch (64 seqs x 33 tokens, 0.6B width)", v, 64 * 33)
 
 
 def test_config1_example_prompts_eager_exact_tokens(ckpt_06b):
     """BASELINE.json config 1: 0.6B shapes, enforce_eager, the reference example's two prompt strings
-    (example.py:12-15) + two token-id lists, max_tokens 16, T = 0 => every token is the oracle's argmax for the same
-    history. (The reference runs this case on a CPU torch device; this framework has no CPU path by design — the
+    (example.py:12-15) + two token-id lists, max_tokens 16, T = 0, judged under the margin rule by the CPU oracle.
+    (The reference runs this case on a CPU torch device; this framework has no CPU path by design — the
     product fails loudly without the HIP library — so the case runs on the GPU with the CPU oracle as the judge.)"""
-    from oracle.engine import OracleEngine
-    from oracle.model import OracleQwen3
     from transformers import AutoTokenizer
     tok = AutoTokenizer.from_pretrained(ckpt_06b, use_fast=True)
     strings = ["introduce yourself", "list all prime numbers within 100"]
@@ -240,23 +251,8 @@ def test_config1_example_prompts_eager_exact_tokens(ckpt_06b):
                                 num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True)
     assert [len(o["token_ids"]) for o in outs] == max_tokens and all(isinstance(o["text"], str) for o in outs)
     cfg, w = _oracle_weights_06b("cuda")
-    eng = OracleEngine(OracleQwen3(cfg, w, compiled=True), nblk, 256, max_num_seqs=8)
-    eng.keep_logits = True
-    for p, m in zip(ids, max_tokens):
-        eng.add(p, 0.0, m, True)
-    exact = total = 0
-    worst = 0.0
-    for i, r in enumerate(rec):
-        eng.step(forced_tokens=r["tokens"])
-        o = eng.trace[-1]
-        assert o["is_prefill"] == r["prefill"] and o["tables"] == r["tables"], f"step {i}: schedule differs"
-        for row, t in enumerate(r["tokens"]):
-            gap = float(o["logits"][row].max() - o["logits"][row, t])
-            worst = max(worst, gap)
-            exact += gap == 0.0
-            total += 1
-    print(f"config 1 (0.6B shapes, eager, 2 strings + 2 id lists): {exact}/{total} exact argmax, worst gap {worst:.4f}")
-    assert worst <= TOL and exact >= 0.8 * total
+    _check("config 1 (0.6B shapes, eager, 2 strings + 2 id lists)",
+           _judge_run(cfg, w, ids, max_tokens, rec, nblk, max_num_seqs=8), 64)
 
 
 def test_qwen3_06b_shape_bench_workload_properties(ckpt_06b):
@@ -353,8 +349,6 @@ def test_full_width_layers_greedy_parity_vs_oracle(name, wide, monkeypatch):
     from nano_vllm_amd.weights import write_synthetic_checkpoint
     monkeypatch.setenv("NVL_GEMM_WIDE", wide)
     layers._wide_choice.clear()
-    from oracle.engine import OracleEngine
-    from oracle.model import OracleQwen3
     vocab = 2048
     path = tempfile.mkdtemp(prefix=name.replace("-", "_") + "_")
     write_synthetic_checkpoint(path, name, with_weights=False, vocab_size=vocab, max_position_embeddings=4096)
@@ -364,25 +358,10 @@ def test_full_width_layers_greedy_parity_vs_oracle(name, wide, monkeypatch):
                                 num_kvcache_blocks=24, max_num_seqs=8, dummy_weights=True)
     assert [len(o["token_ids"]) for o in outs] == max_tokens
     cfg, w = _oracle_weights(name, vocab)
-    eng = OracleEngine(OracleQwen3(cfg, w, compiled=True), nblk, 256, max_num_seqs=8)
-    eng.keep_logits = True
-    for p, m in zip(prompts, max_tokens):
-        eng.add(p, 0.0, m, True)
-    exact = total = 0
-    worst = 0.0
-    for i, r in enumerate(rec):
-        eng.step(forced_tokens=r["tokens"])
-        o = eng.trace[-1]
-        assert o["is_prefill"] == r["prefill"] and o["tables"] == r["tables"], f"step {i}: schedule differs"
-        for row, tok in enumerate(r["tokens"]):
-            gap = float(o["logits"][row].max() - o["logits"][row, tok])
-            worst = max(worst, gap)
-            exact += gap == 0.0
-            total += 1
+    v = _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device="cuda", max_num_seqs=8)
     used = sum(layers.wide_choices().values())
     layers._wide_choice.clear()
-    print(f"{name} wide={wide}: {exact}/{total} exact argmax, worst logit gap {worst:.4f}, wide shapes used {used}")
-    assert worst <= TOL and exact >= 0.8 * total
+    _check(f"{name} wide={wide} (wide shapes used {used})", v, sum(max_tokens))
     assert (used > 0) == (wide == "1")
 
 
@@ -446,9 +425,8 @@ def test_prompt_longer_than_the_token_budget_end_to_end(tiny_ckpt):
     outs, rec, nblk = _run_ours(path, prompts, max_tokens, enforce_eager=False, max_model_len=20480,
                                 num_kvcache_blocks=80, max_num_seqs=8, max_num_batched_tokens=16384)
     assert rec[0]["prefill"] and rec[0]["sched"] == [16384] and rec[1]["prefill"] and rec[1]["sched"][0] == 616
-    exact, total, worst = _judge(path, prompts, max_tokens, rec, nblk, max_num_seqs=8, max_num_batched_tokens=16384)
-    print(f"17k-token prompt: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
-    assert worst <= TOL and exact >= 0.9 * total
+    _check("17k-token prompt", _judge(path, prompts, max_tokens, rec, nblk, max_num_seqs=8,
+                                      max_num_batched_tokens=16384), sum(max_tokens))
 
 
 def test_lookahead_and_microbatch_modes_reproduce_the_serial_engine(tiny_ckpt, monkeypatch):

@@ -3,7 +3,8 @@ against the CPU oracle (oracle/ops.py) on identical seeded inputs.
 
 Tolerances: pointwise ops <= 1 bf16 ulp vs the fp32 restatement that rounds where
 the compiled reference rounds (rotary and KV store are bit-exact); attention max-abs-diff
-<= 2e-2 * absmax (flash tolerance; P is rounded to bf16 before P.V in both).
+<= 2e-2 * absmax (flash tolerance; P is rounded to bf16 before P.V in both) PLUS a checksum on the
+softmax log-sum-exp (|dLSE| <= 2e-3: fp32 arithmetic on both sides, only the summation order differs).
 """
 import math
 import os
@@ -353,6 +354,43 @@ def test_paged_attn_decode(ops, hq, hkv, lens):
             assert torch.count_nonzero(o[i]) == 0  # padded rows produce zeros
 
 
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (16, 2)])
+@pytest.mark.parametrize("lens", [[1], [255, 256, 257], [1, 100, 1023, 1024, 1025, 2048, 17, 0, 0, 640], [4096, 3, 0, 700],
+                                  [0, 0, 5, 0, 0, 0, 900, 0]])
+def test_paged_attn_decode_lse_checksum_and_per_step_plan(ops, hq, hkv, lens):
+    """(a) The softmax log-sum-exp the kernel reports (flash-attn's softmax_lse) against the oracle's: a checksum on
+    the normaliser that the 2e-2 * absmax output tolerance cannot see — |dLSE| <= 2e-3 (fp32 arithmetic on exact
+    bf16 products; only the summation order differs). (b) The same launch driven by a per-step plan (nvl_decode_plan)
+    must reproduce the unplanned launch BIT FOR BIT (same grid, same shares, same split partials), also with padded
+    rows (context_len 0) in the middle of the batch."""
+    bs = 256
+    kc, vc, bt = _paged_setup(lens, hkv, bs, seed=120 + len(lens))
+    b = len(lens)
+    q = torch.randn(b, hq, 128, generator=g(121)).to(BF16)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    scale = 128 ** -0.5
+    o_ref, lse_ref = ref.flash_attn_with_kvcache(q.unsqueeze(1), kc, vc, ctx, bt, scale, return_softmax_lse=True)
+    max_ctx = 4096
+    btw = torch.full((b, max_ctx // bs), -1, dtype=torch.int32)
+    btw[:, : bt.shape[1]] = bt
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    dq, dk, dv, dbt, dctx = dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(btw), dev(ctx)
+    lse = torch.zeros(b, hq, dtype=torch.float32, device="cuda")
+    o = ops.paged_attn_decode(dq, dk, dv, dbt, dctx, scale, max_ctx, ws, lse=lse)
+    live = torch.tensor([n > 0 for n in lens])
+    assert torch.isinf(lse.cpu()[~live]).all() and (lse.cpu()[~live] < 0).all()
+    err = (lse.cpu()[live] - lse_ref[live]).abs().max().item()
+    assert err <= 2e-3, err
+    plan = ops.decode_plan(dctx, hq, hkv, max_ctx)
+    lse2 = torch.zeros_like(lse)
+    ws2 = torch.zeros_like(ws)
+    o2 = ops.paged_attn_decode(dq, dk, dv, dbt, dctx, scale, max_ctx, ws2, plan=plan, lse=lse2)
+    if hq // hkv > 1:        # the matrix-core kernel consumes the plan; group size 1 ignores it
+        assert torch.equal(o2, o) and torch.equal(lse2, lse)
+    err = (o2.cpu().float() - o_ref.squeeze(1).float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+
+
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1)])
 @pytest.mark.parametrize("lens", [[1], [255, 256, 257, 33], [1, 100, 1023, 1024, 1025, 2048, 17, 0, 640], [4096, 3, 0, 700]])
 @pytest.mark.parametrize("with_norm", [True, False])
@@ -407,13 +445,27 @@ def test_paged_attn_decode_fused_equals_unfused(ops, hq, hkv, lens, with_norm):
     # and against the CPU oracle directly (token-major caches, flash_attn_with_kvcache semantics)
     live = [i for i, n in enumerate(lens) if n > 0]
     if live:
-        o_ref = ref.flash_attn_with_kvcache(q1.cpu().unsqueeze(1), ref.from_head_major(kc1.cpu()), ref.from_head_major(vc1.cpu()),
-                                            ctx, bt, scale).squeeze(1)
-        d = (o2.cpu().float()[live] - o_ref.float()[live]).abs().max()
-        assert float(d) <= 2e-2 * float(o_ref.float()[live].abs().max())
+        o_ref, lse_ref = ref.flash_attn_with_kvcache(q1.cpu().unsqueeze(1), ref.from_head_major(kc1.cpu()),
+                                                     ref.from_head_major(vc1.cpu()), ctx, bt, scale, return_softmax_lse=True)
+        o_ref = o_ref.squeeze(1)
+        dd = (o2.cpu().float()[live] - o_ref.float()[live]).abs().max()
+        assert float(dd) <= 2e-2 * float(o_ref.float()[live].abs().max())
     for i, n in enumerate(lens):
         if n == 0:
             assert not o2[i].any()
+    # the fused launch driven by the per-step plan, reporting its softmax LSE: same bits as the unplanned launch
+    # (matrix-core kernel), caches again identical, LSE (new token included) against the oracle's
+    kc3, vc3 = dev(kc.clone()), dev(vc.clone())
+    lse = torch.zeros(b, hq, dtype=torch.float32, device="cuda")
+    plan = ops.decode_plan(d["ctx"], hq, hkv, max_ctx)
+    o3 = ops.paged_attn_decode_fused(d["qkv"], d["qw"], d["kw"], 1e-6, d["table"], kc3, vc3, d["bt"], d["ctx"], hq, scale,
+                                     max_ctx, torch.zeros_like(ws), plan=plan, lse=lse)
+    torch.cuda.synchronize()
+    assert torch.equal(kc3, kc2) and torch.equal(vc3, vc2)
+    if hq // hkv > 1:
+        assert torch.equal(o3, o2)
+    if live:
+        assert float((lse.cpu()[live] - lse_ref[live]).abs().max()) <= 2e-3
 
 
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (16, 2), (8, 1), (32, 8)])
@@ -431,11 +483,15 @@ def test_paged_attn_decode_large_batch(ops, hq, hkv):
     max_ctx = 4096
     btw = torch.full((256, max_ctx // bs), -1, dtype=torch.int32)
     btw[:, : bt.shape[1]] = bt
+    planned = ops.decode_plan(dev(ctx), hq, hkv, max_ctx)
     ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(256, hq, max_ctx), dtype=torch.uint8, device="cuda")
     o = ops.paged_attn_decode(dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(btw), dev(ctx), scale,
                               max_ctx, ws)
     err = (o.cpu().float() - o_ref.float()).abs().max().item()
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+    o_planned = ops.paged_attn_decode(dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(btw), dev(ctx),
+                                      scale, max_ctx, torch.zeros_like(ws), plan=planned)
+    assert torch.equal(o_planned, o)
 
 
 # ------------------------------------------------------------------------------------------
@@ -454,12 +510,16 @@ def test_prefill_contiguous(ops, hq, hkv, lens):
     v = qkv[:, 2 * hkv * 128:].view(n, hkv, 128)
     cu = _cu(lens)
     scale = 128 ** -0.5
-    o_ref = ref.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, scale, True, None)
+    o_ref, lse_ref = ref.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, scale, True, None,
+                                                return_softmax_lse=True)
     dqkv = dev(qkv)
+    lse = torch.zeros(n, hq, dtype=torch.float32, device="cuda")
     o = ops.attn_prefill_varlen(dev(q), dqkv[:, hkv * 128: 2 * hkv * 128].view(n, hkv, 128),
-                                dqkv[:, 2 * hkv * 128:].view(n, hkv, 128), dev(cu), dev(cu), max(lens), scale)
+                                dqkv[:, 2 * hkv * 128:].view(n, hkv, 128), dev(cu), dev(cu), max(lens), scale, lse=lse)
     err = (o.cpu().float() - o_ref.float()).abs().max().item()
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+    # checksum on the softmax normaliser (flash-attn's softmax_lse), which the output tolerance cannot see
+    assert float((lse.cpu() - lse_ref).abs().max()) <= 2e-3
 
 
 def test_prefill_many_short_sequences(ops):
@@ -492,11 +552,14 @@ def test_prefill_paged_prefix(ops, hq, hkv, lq_lk):
     q = torch.randn(sum(lqs), hq, 128, generator=gen).to(BF16)
     cuq, cuk = _cu(lqs), _cu(lks)
     scale = 128 ** -0.5
-    o_ref = ref.flash_attn_varlen_func(q, kc, vc, max(lqs), cuq, max(lks), cuk, scale, True, bt)
+    o_ref, lse_ref = ref.flash_attn_varlen_func(q, kc, vc, max(lqs), cuq, max(lks), cuk, scale, True, bt,
+                                                return_softmax_lse=True)
+    lse = torch.zeros(sum(lqs), hq, dtype=torch.float32, device="cuda")
     o = ops.attn_prefill_varlen(dev(q), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(cuq), dev(cuk),
-                                max(lqs), scale, block_tables=dev(bt))
+                                max(lqs), scale, block_tables=dev(bt), lse=lse)
     err = (o.cpu().float() - o_ref.float()).abs().max().item()
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+    assert float((lse.cpu() - lse_ref).abs().max()) <= 2e-3
 
 
 def test_prefill_softmax_rescale_branch(ops):
@@ -510,10 +573,12 @@ def test_prefill_softmax_rescale_branch(ops):
     k[300] = (q[400] * 4).to(BF16)  # key 300 dominates query 400 (and is visible to it)
     cu = _cu(lens)
     scale = 128 ** -0.5
-    o_ref = ref.flash_attn_varlen_func(q, k, v, 512, cu, 512, cu, scale, True, None)
-    o = ops.attn_prefill_varlen(dev(q), dev(k), dev(v), dev(cu), dev(cu), 512, scale)
+    o_ref, lse_ref = ref.flash_attn_varlen_func(q, k, v, 512, cu, 512, cu, scale, True, None, return_softmax_lse=True)
+    lse = torch.zeros(512, hq, dtype=torch.float32, device="cuda")
+    o = ops.attn_prefill_varlen(dev(q), dev(k), dev(v), dev(cu), dev(cu), 512, scale, lse=lse)
     err = (o.cpu().float() - o_ref.float()).abs().max().item()
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+    assert float((lse.cpu() - lse_ref).abs().max()) <= 1e-2          # scores up to ~180 here: fp32 spacing 1.5e-5 x sums
 
 
 
