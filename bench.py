@@ -391,7 +391,8 @@ def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
     from tools.attn_replay import replay
     geo = runner.geo
     hq, hkv, L = geo["heads"], geo["kv_heads"], geo["layers"]
-    r = replay(torch, runner.kv_cache, rec["samples"], hq, hkv, runner.config.max_model_len, runner.decode_ws, fused=True)
+    r = replay(torch, runner.kv_cache, rec["samples"], hq, hkv, runner.config.max_model_len, runner.decode_ws, fused=True,
+               plan=runner.use_plan)
     achieved = r["achieved_GBps"]
     # the kernel nvl_paged_attn_decode_fused dispatches to for this geometry (attn_decode.hip: decode_common)
     G, fp8 = hq // hkv, runner.kv_cache.element_size() == 1

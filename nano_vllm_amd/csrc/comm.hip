@@ -74,7 +74,8 @@ __device__ __forceinline__ void st_sys(uint32_t* p, uint32_t v) {
 constexpr uint32_t kSpinLimit = 40u * 1000u * 1000u;
 
 // Every thread of the workgroup calls both. `which` = 0 / 1 selects flag0 / flag1.
-// c.fences == 0 ("lean", what the engine selects; NVL_TP_P2P_FENCES=1 restores the fences): everything a peer reads
+// c.fences == 0 ("lean": selected by tp.init_p2p only after a randomised stress self-check of BOTH flavours has passed
+// on the topology at hand; NVL_TP_P2P_HANDOFF=fenced / lean forces one): everything a peer reads
 // lives in UNCACHED memory, so a store that has been acknowledged (vmcnt) is in memory and a load cannot hit a stale
 // line: the per-wave drain + barrier orders payload before flag — the "write-through payload -> vmcnt(0) -> flag" form
 // of Guideline 16 (R1) — without the L2 write-back / invalidate of a system-scope fence, four of which per call were
@@ -296,12 +297,13 @@ extern "C" int nvl_allreduce_create(int rank, int world, int64_t max_bytes, void
   cm->dev.world = world;
   cm->dev.data_off = kFlagBytes;
   cm->dev.red_off = kFlagBytes + data;
-  cm->dev.fences = 1;      // library default: fenced; the engine (ops.P2PComm) selects the lean form
+  cm->dev.fences = 1;      // fenced unless the caller has validated the lean hand-off on ITS topology (tp.init_p2p)
   void* p = nullptr;
-  if (hipExtMallocWithFlags(&p, cm->total_bytes, hipDeviceMallocUncached) != hipSuccess || !p) {
+  const size_t total_bytes = cm->total_bytes;
+  if (hipExtMallocWithFlags(&p, total_bytes, hipDeviceMallocUncached) != hipSuccess || !p) {
     (void)hipGetLastError();
     delete cm;
-    nvl_set_error("nvl_allreduce_create: cannot allocate %zu B of uncached device memory", cm->total_bytes);
+    nvl_set_error("nvl_allreduce_create: cannot allocate %zu B of uncached device memory", total_bytes);
     return NVL_ELAUNCH;
   }
   if (hipMemset(p, 0, cm->total_bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {

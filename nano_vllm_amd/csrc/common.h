@@ -64,7 +64,12 @@ __device__ __forceinline__ u32x4_t pack8(const float* f) {
 
 // ---- OCP fp8 (e4m3fn: what gfx950's conversion instructions implement) <-> fp32, 4 values per dword ----------
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+// v_cvt_pk_fp8_f32 does not saturate: a magnitude above the largest e4m3 value (448) would be stored as NaN and
+// poison every later decode step of that sequence, so the operands are clamped first (what hip_fp8's software path
+// does as well); in-range values are unaffected (bit-exact with torch's float8_e4m3fn cast, tests/test_kernels_gpu.py).
+__device__ __forceinline__ float clamp_e4m3(float v) { return __builtin_amdgcn_fmed3f(v, 448.f, -448.f); }
 __device__ __forceinline__ unsigned int pack_fp8x4(float a, float b, float c, float d) {
+  a = clamp_e4m3(a); b = clamp_e4m3(b); c = clamp_e4m3(c); d = clamp_e4m3(d);
   unsigned int w = 0;
   w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
   w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);

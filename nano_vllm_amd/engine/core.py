@@ -83,16 +83,20 @@ class LLMEngine:
         for p in self.ps:
             p.join()
 
-    def add_request(self, prompt: str | list[int], sampling_params: SamplingParams):
+    def _checked_prompt(self, prompt: str | list[int], sampling_params: SamplingParams) -> list[int]:
+        """Tokenise and validate one request; no side effects."""
         if isinstance(prompt, str):
             prompt = self.tokenizer.encode(prompt)
         assert len(prompt) > 0, "empty prompt"
         # the staging block tables and the RoPE table are sized by max_model_len: a request that would outgrow
-        # them is refused here instead of failing mid-generation
+        # them is refused here instead of failing mid-generation (stricter than the reference, which fails later)
         assert len(prompt) + sampling_params.max_tokens <= self.config.max_model_len, (
             f"prompt ({len(prompt)} tokens) + max_tokens ({sampling_params.max_tokens}) exceeds "
             f"max_model_len ({self.config.max_model_len})")
-        self.scheduler.add(Sequence(prompt, sampling_params))
+        return prompt
+
+    def add_request(self, prompt: str | list[int], sampling_params: SamplingParams):
+        self.scheduler.add(Sequence(self._checked_prompt(prompt, sampling_params), sampling_params))
 
     def step(self):
         seqs, is_prefill = self.scheduler.schedule()
@@ -120,8 +124,13 @@ class LLMEngine:
         then step N is collected, and postprocess (token values filled in afterwards), schedule and staging of
         step N+2 run while the GPU works. The GPU queue never drains between decode steps. With `ignore_eos` the
         scheduler and block manager go through exactly the serial loop's operations; a sequence that samples EOS
-        is discovered one step late and finished retroactively (sched.Scheduler.fill_tokens): its outputs are the
-        serial loop's, only its last step's row was computed for nothing. Finished sequences of a lookahead step
+        is discovered one step late and finished retroactively (sched.Scheduler.fill_tokens): its own outputs are the
+        serial loop's, only its last step's row was computed for nothing. At T = 0 (and with `ignore_eos` at any
+        temperature) every sequence's outputs are the serial loop's. At T > 0 WITHOUT `ignore_eos` they are not
+        stream-identical: the sampler's counter-based draw is keyed by (step, batch row), the retroactively finished
+        sequence still occupies a row of step N+1, so the sequences behind it in that batch draw other random
+        numbers than in the serial loop (same distribution, different stream; NVL_LOOKAHEAD=0 gives the serial
+        stream). Finished sequences of a lookahead step
         are reported by the next call.
         `pending`: None, or (seqs, is_prefill, staged) scheduled by the previous call.
         Returns (finished outputs, num_tokens, pending for the next call)."""
@@ -173,8 +182,10 @@ class LLMEngine:
         pbar = tqdm(total=len(prompts), desc="Generating", dynamic_ncols=True, disable=not use_tqdm)
         if not isinstance(sampling_params, list):
             sampling_params = [sampling_params] * len(prompts)
-        for prompt, sp in zip(prompts, sampling_params):
-            self.add_request(prompt, sp)
+        # validate EVERY request before enqueueing ANY: a refused request must not leave its predecessors queued
+        checked = [self._checked_prompt(prompt, sp) for prompt, sp in zip(prompts, sampling_params)]
+        for prompt, sp in zip(checked, sampling_params):
+            self.scheduler.add(Sequence(prompt, sp))
         done: dict[int, list[int]] = {}
         prefill_tps = decode_tps = 0.0
         pending = None                      # batch already scheduled (and maybe staged) by the lookahead

@@ -269,11 +269,11 @@ class ModelRunner:
                 init_dummy_weights(self.model, hf, config.seed)
             else:
                 load_model(self.model, config.model)
-            self.sampler = Sampler(seed=config.seed)
+            self.sampler = Sampler(seed=config.seed, max_rows=config.max_num_seqs)
             # decode micro-batching (see _forward_decode): second chain's stream, sampler and workspace
             self.microbatches = int(os.environ.get("NVL_MICROBATCHES", "1")) if self.world_size == 1 else 1
             self.side_stream = torch.cuda.Stream(device=self.device) if self.microbatches > 1 else None
-            self.sampler_b = Sampler(seed=config.seed + 0x9E3779B9)
+            self.sampler_b = Sampler(seed=config.seed + 0x9E3779B9, max_rows=config.max_num_seqs)
             self._alloc_stages()
             self.warmup_model()
             self.allocate_kv_cache()

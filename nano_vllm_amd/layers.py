@@ -173,9 +173,10 @@ class Attention(nn.Module):
 class Sampler(nn.Module):
     """Exponential-race categorical sampling in one pass; temperature 0 => argmax (extension)."""
 
-    def __init__(self, seed: int = 0):
+    def __init__(self, seed: int = 0, max_rows: int = 512):
         super().__init__()
         self.seed = seed
+        self.max_rows = max_rows              # rows of the vocab-parallel winner buffers, allocated ONCE (graph-safe)
         self.calls = 0
         self._ws = None
         self._lm_ws = None
@@ -232,11 +233,18 @@ class Sampler(nn.Module):
         return out
 
     def _pair_buffers(self, b: int, size: int, device) -> None:
-        if getattr(self, "_pairs", None) is None or self._pairs.shape[1] < b or self._pairs.device != device:
-            rows = max(b, 512)
-            # whole fixed-size buffers travel (4 KiB at 512 rows): shape-independent => graph-safe
-            self._mine = torch.zeros((rows, 2), dtype=torch.int32, device=device)
-            self._pairs = torch.zeros((size, rows, 2), dtype=torch.int32, device=device)
+        """Select (allocating on first use, never regrowing) the {key, index} winner buffers for a b-row step:
+        a 512-row pair for every captured decode step (4 KiB per rank travels: the P2P all-gather's limit, and a
+        shape-independent message => graph-safe), and a `max_rows` pair for prefill steps with more sequences than
+        that (never captured). A regrow would leave captured graphs pointing at freed memory."""
+        if getattr(self, "_bufs", None) is None or self._bufs_device != device:
+            self._bufs, self._bufs_device = {}, device
+        rows = 512 if b <= 512 else max(self.max_rows, b)
+        if rows not in self._bufs:
+            assert rows == 512 or not torch.cuda.is_current_stream_capturing()
+            self._bufs[rows] = (torch.zeros((rows, 2), dtype=torch.int32, device=device),
+                                torch.zeros((size, rows, 2), dtype=torch.int32, device=device))
+        self._mine, self._pairs = self._bufs[rows]
 
     def forward_shard(self, logits: torch.Tensor, temperatures: torch.Tensor, col_offset: int, out: torch.Tensor,
                       offset_dev: torch.Tensor | None = None) -> torch.Tensor:
@@ -318,11 +326,12 @@ _flush: dict[int, torch.Tensor] = {}
 
 
 def _scratch(nbytes: int, device: torch.device) -> torch.Tensor | None:
-    """Split-K slab scratch of the wide kernel's bf16 / SiLU modes: one tensor per distinct size, never freed or
-    regrown (captured graphs hold its address)."""
+    """Split-K slab scratch of the wide kernel's bf16 / SiLU modes: one tensor per distinct (size, stream), never freed
+    or regrown (captured graphs hold its address). Per STREAM because two decode chains may run the same shapes
+    concurrently (NVL_MICROBATCHES=2: two branches of one graph, captured from two streams) and must not share slabs."""
     if not nbytes:
         return None
-    key = (nbytes, device.index)
+    key = (nbytes, device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _wide_scratch.get(key)
     if t is None:
         t = _wide_scratch[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)

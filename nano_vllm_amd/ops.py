@@ -527,10 +527,18 @@ class P2PComm:
             self.close()
             raise err
         self.max_bytes = int(lib().nvl_allreduce_max_bytes(self._h))
-        # Hand-off flavour: lean by default (per-wave store drains; the shared buffer is uncached, so an acknowledged
-        # store is in memory and a load cannot hit a stale line); NVL_TP_P2P_FENCES=1 adds the system-scope
-        # release / acquire fences back (14.7 -> 8.7 us per 131 x 5120 all-reduce without them, profiles/r02_p2p_bench_w2.json)
-        _check(lib().nvl_allreduce_set_fences(self._h, 1 if os.environ.get("NVL_TP_P2P_FENCES", "0") == "1" else 0))
+        # Hand-off flavour: FENCED (system-scope release / acquire around every flag) until somebody has validated
+        # the lean form — per-wave store drains only, resting on the shared buffer being uncached on both sides of a
+        # link — on the topology at hand: tp.init_p2p does that with a randomised stress run and then calls
+        # set_handoff("lean") (14.7 -> 8.7 us per 131 x 5120 all-reduce, profiles/r02_p2p_bench_w2.json).
+        self.handoff = "fenced"
+        _check(lib().nvl_allreduce_set_fences(self._h, 1))
+
+    def set_handoff(self, flavour: str) -> None:
+        """"fenced" | "lean" — must be called with the same value on every rank, between collectives."""
+        assert flavour in ("fenced", "lean")
+        _check(lib().nvl_allreduce_set_fences(self._h, 1 if flavour == "fenced" else 0))
+        self.handoff = flavour
 
     def input_buffer(self, rows: int, hidden: int, device) -> torch.Tensor:
         """A [rows, hidden] bf16 tensor that IS this rank's shared input region: a GEMM that writes its output

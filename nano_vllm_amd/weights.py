@@ -33,6 +33,7 @@ QWEN3_SHAPES = {
     "qwen3-tiny": (256, 512, 2, 4, 2, True),
     "qwen3-tiny-untied": (256, 512, 3, 8, 2, False),     # G = 4, separate lm_head (8B-like)
     "qwen3-tiny-g8": (512, 768, 2, 8, 1, False),          # G = 8, one kv head (32B / TP=8 per-rank shape)
+    "qwen3-tiny-kv8": (512, 1024, 2, 16, 8, False),       # 8 kv heads: shards down to 1 kv head per rank at TP = 8
     # two full-width layers of the large models (tests: the layer code paths real 8B / 32B widths take)
     "qwen3-8b-2l": (4096, 12288, 2, 32, 8, False),
     "qwen3-32b-2l": (5120, 25600, 2, 64, 8, False),

@@ -27,6 +27,7 @@ def _run_ours(path, prompts, max_tokens, capture_logits=False, **kw):
     orig = runner.call
     logits_log = []
     if capture_logits:
+        assert kw.get("enforce_eager"), "logits are captured by Python code: a replayed hipGraph runs none"
         runner.sampler.capture = logits_log                # every step's logits, whichever sampling path runs
 
     def snap(seqs, is_prefill):
@@ -187,7 +188,7 @@ def test_qwen3_06b_shape_greedy_parity_vs_cpu_oracle_and_device_oracle_agrees(ck
     prompts = _prompts(3, 20, 300, 10000, seed=21)
     max_tokens = [16, 14, 18]
     outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, enforce_eager=False, max_model_len=1024,
-                                num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True, capture_logits=True)
+                                num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True)
     cfg, w = _oracle_weights_06b("cuda")
     v = _judge_run(cfg, w, prompts, max_tokens, rec, nblk, max_num_seqs=8)
     _check("0.6B shapes (CPU oracle)", v, sum(max_tokens))

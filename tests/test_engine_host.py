@@ -235,6 +235,12 @@ def test_over_length_request_is_refused_up_front():
     with pytest.raises(AssertionError, match="max_model_len"):
         eng.add_request(list(range(500)), SamplingParams(max_tokens=13))
     eng.add_request(list(range(500)), SamplingParams(max_tokens=12))
+    # generate() validates every request before it enqueues any: a refused batch leaves nothing behind
+    eng = _engine(True, max_num_seqs=4, max_model_len=512, num_kvcache_blocks=8)
+    with pytest.raises(AssertionError, match="max_model_len"):
+        eng.generate([list(range(10)), list(range(500))], [SamplingParams(max_tokens=5), SamplingParams(max_tokens=13)],
+                     use_tqdm=False)
+    assert eng.scheduler.is_finished() and not eng.scheduler.waiting
 
 
 def test_control_channel_ring_order_backpressure_and_payloads():
@@ -410,14 +416,16 @@ def test_p2p_comm_construction_always_joins_its_collectives(mode, monkeypatch):
 
     if mode == "ok":
         c = ops.P2PComm(0, 2, 1 << 20, exchange, barrier)
-        assert c.max_bytes == 1 << 20 and fake.calls == ["create", "uid", "connect", "fences=0"]
-        assert c.fits(16, 1024) and not c.fits(16, 1028)
+        assert c.max_bytes == 1 << 20 and fake.calls == ["create", "uid", "connect", "fences=1"]   # fenced until validated
+        assert c.fits(16, 1024) and not c.fits(16, 1028) and c.handoff == "fenced"
+        c.set_handoff("lean")
+        assert fake.calls[-1] == "fences=0" and c.handoff == "lean"
         c.close()
         assert fake.calls[-1] == "destroy"
     else:
         with pytest.raises(ops.NvlError):
             ops.P2PComm(0, 2, 1 << 20, exchange, barrier)
-        assert "fences=0" not in fake.calls
+        assert "fences=0" not in fake.calls and "fences=1" not in fake.calls
         if mode == "create_fails":
             assert joined[0] == ("exchange", b"\0" * 64)          # an all-zero token tells the peers
             assert "connect" not in fake.calls

@@ -693,6 +693,16 @@ def test_fp8_kv_store_matches_torch_cast_bit_for_bit(ops, n, h, hkv):
     ref_k[slots[keep].long()] = k[keep]
     got = kc.cpu().view(torch.uint8).view(nblk, hkv, bs, 128).permute(0, 2, 1, 3).reshape(nblk * bs, hkv, 128)
     assert torch.equal(got, ref_k.to(torch.float8_e4m3fn).view(torch.uint8))
+    # magnitudes beyond the e4m3 range saturate at +-448 instead of turning into NaN (which would poison every later
+    # decode step of the sequence that reads the row back)
+    big = torch.zeros(n, hkv, 128, dtype=BF16)
+    big[-1, 0, :4] = torch.tensor([1000.0, -3.0e4, 448.0, 460.0]).to(BF16)
+    kc.zero_()
+    vc.zero_()
+    s2 = torch.arange(n, dtype=torch.int32)
+    ops.store_kvcache(dev(big), dev(big), kc, vc, dev(s2))
+    row = kc.cpu().float().view(nblk, hkv, bs, 128)[(n - 1) // bs, 0, (n - 1) % bs, :4]
+    assert row.tolist() == [448.0, -448.0, 448.0, 448.0] and not torch.isnan(kc.cpu().float()).any()
 
 
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (16, 2), (64, 8)])

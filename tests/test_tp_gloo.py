@@ -1,4 +1,4 @@
-"""Tensor-parallel semantics on CPU: 2 processes, gloo backend (the N>1 path; RCCL needs GPUs).
+"""Tensor-parallel semantics on CPU: 2, 4 and 8 processes, gloo backend (the N>1 path; RCCL needs GPUs).
 
 Each rank builds the sharded layers, loads its shard from the SAME full checkpoint tensors via
 the layers' weight_loader (shard layout of layers/linear.py:54-156, embed_head.py:27-32), runs
@@ -36,7 +36,8 @@ def _worker(rank, world, port, q):
         from nano_vllm_amd import layers as L
         from nano_vllm_amd.attn_meta import reset_context, set_context
         g = torch.Generator().manual_seed(0)
-        hidden, heads, kv, d, inter, vocab, n = 64, 4, 2, 16, 96, 50, 7
+        # 16 query / 8 kv heads (Qwen3's kv-head count): 8 / 4 / 2 query and 4 / 2 / 1 kv heads per rank at TP 2 / 4 / 8
+        hidden, heads, kv, d, inter, vocab, n = 64, 16, 8, 16, 96, 56, 7
         x = torch.randn(n, hidden, generator=g)
         wq, wk, wv = (torch.randn(s, hidden, generator=g) for s in (heads * d, kv * d, kv * d))
         wo = torch.randn(hidden, heads * d, generator=g)
@@ -102,8 +103,9 @@ def _worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(300)
-def test_sharded_layers_match_unsharded_world2():
-    world, port = 2, _free_port()
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_layers_match_unsharded(world):
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]

@@ -83,8 +83,9 @@ def _comm_worker(rank, world, port, q):
             calls += 2
         # zero-copy input (the GEMM writes its partial sums straight into the shared region) and the lean hand-off
         # (store drains instead of system-scope fences: the region is uncached), all four combinations
+        assert comm.handoff == "fenced"                # a fresh communicator is fenced until somebody validates lean
         for lean in (0, 1):
-            ops.lib().nvl_allreduce_set_fences(comm._h, 0 if lean else 1)
+            comm.set_handoff("lean" if lean else "fenced")
             dist.barrier()
             for it, (rows, hid) in enumerate([(131, 5120), (2, 5120), (64, 4096)]):
                 if hid % (8 * world):
@@ -103,7 +104,7 @@ def _comm_worker(rank, world, port, q):
                 w1 = torch.ones(hid, dtype=torch.bfloat16, device=dev)
                 comm.all_reduce_add_rmsnorm(x2, res, w1, 1e-6)
                 errs[f"zero_copy_norm_lean{lean}_{rows}x{hid}"] = float((res.cpu().float() - exact.float()).abs().max())
-        ops.lib().nvl_allreduce_set_fences(comm._h, 1)
+        comm.set_handoff("fenced")
         dist.barrier()
         # small all-gather (the sampler's winners): 512 rows x 8 bytes
         mine = torch.full((512, 2), rank + 1, dtype=torch.int32, device=dev)
@@ -143,8 +144,9 @@ def _comm_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_p2p_collectives_between_processes(world):
+    """world 8: the W = 8 two-shot path of comm.hip (kMaxWorld ranks, 64-element column slices)."""
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context("spawn")
@@ -177,7 +179,8 @@ def tiny_ckpt():
 @pytest.mark.timeout(900)
 @pytest.mark.parametrize("mode", ["p2p-graph", "p2p-eager", "group-eager"])
 def test_tp2_engine_greedy_parity_on_one_gpu(tiny_ckpt, mode, monkeypatch):
-    from test_e2e_gpu import _judge, _prompts, _run_ours
+    """(p2p modes: tp.init_p2p runs its full 1,000-epoch stress self-check of both hand-off flavours here.)"""
+    from test_e2e_gpu import _check, _judge, _prompts, _run_ours
     monkeypatch.setenv("NVL_TP_SHARE_GPU", "1")
     monkeypatch.setenv("NVL_TP_BACKEND", "gloo")
     monkeypatch.setenv("NVL_TP_PORT", str(_free_port()))
@@ -187,9 +190,112 @@ def test_tp2_engine_greedy_parity_on_one_gpu(tiny_ckpt, mode, monkeypatch):
     outs, rec, nblk = _run_ours(tiny_ckpt, prompts, max_tokens, enforce_eager=mode != "p2p-graph", max_model_len=2048,
                                 num_kvcache_blocks=32, max_num_seqs=16, tensor_parallel_size=2)
     assert [len(o["token_ids"]) for o in outs] == max_tokens
-    exact, total, worst = _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, max_num_seqs=16)
-    print(f"tiny TP=2 {mode}: {exact}/{total} exact argmax, worst logit gap {worst:.4f}")
-    assert worst <= 0.15 and exact >= 0.9 * total
+    _check(f"tiny TP=2 {mode}", _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, max_num_seqs=16), sum(max_tokens))
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("tp_size", [4, 8])
+def test_tp4_tp8_engine_greedy_parity_on_one_gpu(tp_size, monkeypatch):
+    """The whole TP engine at degrees 4 and 8 (every rank a process on cuda:0): a 16 / 8-head model shards down to
+    4 / 2 query heads and 2 / 1 kv heads per rank (models/qwen3.py:29-38 at TP = 8), the vocabulary into 8 shards whose
+    sampling winners are merged on every rank, the W = 8 all-reduce kernels run inside the captured decode graph —
+    judged against the oracle under the same margin rule as TP = 1."""
+    from nano_vllm_amd.weights import write_synthetic_checkpoint
+    from test_e2e_gpu import _check, _judge, _prompts, _run_ours
+    path = tempfile.mkdtemp(prefix="qwen3tiny_kv8_")
+    write_synthetic_checkpoint(path, "qwen3-tiny-kv8", seed=0, vocab_size=512, max_position_embeddings=2048)
+    monkeypatch.setenv("NVL_TP_SHARE_GPU", "1")
+    monkeypatch.setenv("NVL_TP_BACKEND", "gloo")
+    monkeypatch.setenv("NVL_TP_PORT", str(_free_port()))
+    monkeypatch.setenv("NVL_TP_P2P", "1")
+    monkeypatch.setenv("NVL_TP_P2P_STRESS_EPOCHS", "60")      # 4 / 8 processes time-slice ONE GPU here
+    prompts = _prompts(4, 5, 400, 512, seed=13)
+    max_tokens = [10, 6, 12, 3]
+    outs, rec, nblk = _run_ours(path, prompts, max_tokens, enforce_eager=False, max_model_len=1024,
+                                num_kvcache_blocks=16, max_num_seqs=8, tensor_parallel_size=tp_size)
+    assert [len(o["token_ids"]) for o in outs] == max_tokens
+    _check(f"tiny-kv8 TP={tp_size}", _judge(path, prompts, max_tokens, rec, nblk, max_num_seqs=8), sum(max_tokens))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# RCCL: the "nccl" branches of tp.py, executed with a 1-rank group on the one GPU (RCCL refuses two ranks per device)
+def _rccl_worker(port, q):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", f"tcp://127.0.0.1:{port}", world_size=1, rank=0, device_id=dev)
+    res = {}
+    try:
+        from nano_vllm_amd import ops, tp
+        ops.load_library()
+        tp.init(0, 1, issue_collectives=True)
+        res["backend"] = tp._backend
+        res["capturable"] = tp.capturable()
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(4096, 256, generator=g).to(torch.bfloat16).to(dev)
+        w = torch.randn(512, 256, generator=g).to(torch.bfloat16).to(dev)
+        # prefill-sized: GEMM chunks on the compute stream, RCCL all-reduce of chunk i on the side stream
+        y = tp.linear_allreduce(x, w)
+        torch.cuda.synchronize()
+        res["overlap_err"] = float((y.float() - F.linear(x, w).float()).abs().max())
+        res["side_stream_used"] = tp._side_stream is not None
+        # decode-sized: inline all-reduce; host tensors go through a device copy; small all-gather into a tensor
+        small = torch.randn(7, 256, generator=g).to(torch.bfloat16).to(dev)
+        res["small_err"] = float((tp.all_reduce(small.clone()).float() - small.float()).abs().max())
+        host = torch.tensor([5], dtype=torch.int64)
+        tp.group_all_reduce(host, op=dist.ReduceOp.MIN)
+        res["host_min"] = int(host.item())
+        mine = torch.arange(64, dtype=torch.int32, device=dev).view(32, 2)
+        allp = torch.zeros(1, 32, 2, dtype=torch.int32, device=dev)
+        tp.all_gather_small(mine, allp)
+        res["gather_ok"] = bool((allp[0] == mine).all())
+        # an RCCL all-reduce captured into a hipGraph next to one of our kernels, replayed
+        buf = torch.zeros(16, 256, dtype=torch.bfloat16, device=dev)
+        wn = torch.ones(256, dtype=torch.bfloat16, device=dev)
+        out = torch.empty_like(buf)
+        tp.all_reduce(buf)                                    # warm-up: communicator + stream set-up outside the capture
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            tp.all_reduce(buf)
+            ops.rmsnorm(buf, wn, 1e-6, out=out)
+        worst = 0.0
+        for i in range(3):
+            src = torch.randn(16, 256, generator=g).to(torch.bfloat16)
+            buf.copy_(src)
+            graph.replay()
+            torch.cuda.synchronize()
+            ref = src.float() * torch.rsqrt(src.float().pow(2).mean(-1, keepdim=True) + 1e-6)
+            worst = max(worst, float((out.cpu().float() - ref).abs().max()))
+        res["graph_err"] = worst
+        tp.shutdown()
+    except Exception as ex:  # noqa: BLE001 - reported to the parent
+        res["error"] = repr(ex)
+    finally:
+        q.put(res)
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_code_paths_with_a_one_rank_group():
+    """north star: "RCCL all-reduce over xGMI overlapped on a side HIP stream" (linear.py:153-156, model_runner.py:26).
+    One GPU cannot host two RCCL ranks, so the RCCL branches of tp.py run here with a 1-rank "nccl" group in
+    issue_collectives mode: RCCL initialisation, `linear_allreduce`'s chunked GEMM / side-stream all-reduce pipeline
+    (events both ways), the inline all-reduce, the host-tensor and all-gather branches, and an RCCL all-reduce
+    captured into a hipGraph together with one of our kernels (what `tp.capturable()` promises for this backend)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    res = q.get(timeout=240)
+    p.join(60)
+    assert "error" not in res, res
+    assert res["backend"] == "nccl" and res["capturable"] and res["side_stream_used"]
+    assert res["overlap_err"] == 0.0 and res["small_err"] == 0.0 and res["host_min"] == 5 and res["gather_ok"]
+    assert res["graph_err"] <= 0.05
 
 
 @pytest.mark.timeout(900)

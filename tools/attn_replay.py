@@ -66,10 +66,13 @@ def bench_decode_batches(num_seqs: int = 256, num_blocks: int = 9380, every: int
     return samples, dict(decode_steps=steps, prefill_steps=prefills, ctx_tokens=ctx_tokens, max_block=max_block)
 
 
-def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: int = 2, fused: bool = False):
+def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: int = 2, fused: bool = False,
+           plan: bool = True):
     """Time nvl_paged_attn_decode (main kernel + split combine) on the recorded batches.
     kv_cache: [2, L, num_blocks, Hkv, block, 128]. Block ids are folded into the cache with a
-    modulo when the cache is smaller than the pool the schedule was recorded with."""
+    modulo when the cache is smaller than the pool the schedule was recorded with.
+    plan: as the engine does, one nvl_decode_plan per batch (outside the timed bracket: it is one ~4 us launch per
+    STEP, not per layer) shared by the L layer launches."""
     from nano_vllm_amd import ops
     L, nblk = kv_cache.shape[1], kv_cache.shape[2]
     dev = kv_cache.device
@@ -91,15 +94,16 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
         ctx_d = torch.from_numpy(np.ascontiguousarray(ctx)).to(dev)
         bt_d = torch.from_numpy(np.ascontiguousarray(bt)).to(dev)
         q = q_all[:n]
+        step_plan = ops.decode_plan(ctx_d, hq, hkv, max_ctx) if plan else None
         for _ in range(reps):                       # keep the last rep (caches are 100s of MB: nothing stays warm)
             start.record()
             for layer in range(L):
                 if fused:
                     ops.paged_attn_decode_fused(qkv_all[:n], nw, nw, 1e-6, table, kv_cache[0, layer], kv_cache[1, layer],
-                                                bt_d, ctx_d, hq, scale, max_ctx, ws, out=out[:n])
+                                                bt_d, ctx_d, hq, scale, max_ctx, ws, out=out[:n], plan=step_plan)
                 else:
                     ops.paged_attn_decode(q, kv_cache[0, layer], kv_cache[1, layer], bt_d, ctx_d, scale, max_ctx, ws,
-                                          out=out[:n])
+                                          out=out[:n], plan=step_plan)
             stop.record()
             torch.cuda.synchronize()
         total_ms += start.elapsed_time(stop)
@@ -118,6 +122,7 @@ def main():
     ap.add_argument("--reps", type=int, default=2)
     ap.add_argument("--pool-blocks", type=int, default=9380, help="KV pool the schedule is recorded with")
     ap.add_argument("--fused", action="store_true", help="time nvl_paged_attn_decode_fused (norm+rope+store inside)")
+    ap.add_argument("--no-plan", action="store_true", help="every launch derives its own schedule (no nvl_decode_plan)")
     ap.add_argument("--layer-major", action="store_true", help="cache laid out [L, 2, blocks, ...] instead of [2, L, blocks, ...]")
     ap.add_argument("--fp8", action="store_true", help="OCP fp8 e4m3 KV cache (opt-in extension; 128-byte rows)")
     ap.add_argument("--cache-blocks", type=int, default=0,
@@ -142,7 +147,7 @@ def main():
             kv8[:, layer, :used] = kv[:, layer, :used].to(torch.float8_e4m3fn)
         kv = kv8
     ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(512, args.hq, 4096), dtype=torch.uint8, device=dev)
-    r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps, fused=args.fused)
+    r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps, fused=args.fused, plan=not args.no_plan)
     r.update(stats, kernel=f"decode<G={args.hq // args.hkv}, fused={str(args.fused).lower()}, kv={'fp8' if args.fp8 else 'bf16'}>", kv_blocks_used=nblk, samples=len(samples),
              frac_of_8TBps=r["achieved_GBps"] / 8000.0)
     print(json.dumps(r), flush=True)
