@@ -110,6 +110,22 @@ tprun1)
   export NVL_BENCH_SHARE_GPU=1 NVL_BENCH_BACKEND=gloo NVL_BENCH_TP_EXTRA_TIMEOUT=400
   timeout 700 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 1 --warmup 0 --num-seqs 48 --gpu-memory-utilization 0.3 --num-kvcache-blocks 300 --no-cpu-baseline --no-roofline > $OUT/torchrun_dp2_plus_tp_extra.json 2> $OUT/torchrun_dp2.err; echo "torchrun dp2+extra rc=$?"; grep -v "socket.cpp\|Gloo\|amdgpu.ids\|OMP_NUM\|\*\*\*" $OUT/torchrun_dp2.err | tail -8; cut -c1-2500 $OUT/torchrun_dp2_plus_tp_extra.json
   unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND NVL_BENCH_TP_EXTRA_TIMEOUT;;
+pmcg)
+  # HBM traffic (FETCH_SIZE) of the decode-attention kernel at every group size the BASELINE configs run:
+  # G = 2 (Qwen3-0.6B), G = 4 (Qwen3-8B: config 3), G = 8 (Qwen3-32B: configs 4 / 5); bench schedule, one rep
+  for cfg in "16 8 28 8 qwen3-0.6b 2" "32 8 36 8 qwen3-8b 4" "64 8 64 16 qwen3-32b 8"; do
+    set -- $cfg
+    rm -rf /tmp/pmc_g$6
+    (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'decode_' -f csv -d /tmp/pmc_g$6 -o replay -- python $REPO/tools/attn_replay.py --fused --reps 1 --hq $1 --hkv $2 --layers $3 --every $4 > $OUT/replay_under_pmc_g$6.json 2> $OUT/replay_pmc_g$6.err; echo "pmc G=$6 rc=$?")
+    python tools/pmc_summary.py /tmp/pmc_g$6 $OUT/pmc_fetch_summary_g$6.json > /dev/null
+    python tools/pmc_traffic_update.py $OUT/pmc_fetch_summary_g$6.json $OUT/replay_under_pmc_g$6.json $5 "decode_mfma8_kernel<fused, bf16 KV, G=$6>"
+  done
+  cp profiles/pmc_traffic.json $OUT/pmc_traffic.json;;
+tp3)
+  timeout 1500 python -m pytest tests -m gpu -q -rf -s -k "tp or cpu_oracle or fp8_kv_store or rccl or p2p" --durations=8 > $OUT/pytest_tp3.log 2>&1; echo "tp3 pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|argmax|device-resident" $OUT/pytest_tp3.log | tail -30;;
+benchfull)
+  T0=$(date +%s); timeout 1500 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"; tail -c 400 $OUT/bench_full.err; python -c "
+import json; d=json.load(open('$OUT/bench_full.json')); print(round(d['value']), d['roofline']['frac'], d['roofline']['decode_step']['frac_of_8TBps'], d.get('cpu_baseline')); [print(k, v.get('value'), v.get('error'), v.get('wall_s_incl_engine_start'), (v.get('roofline') or {}).get('frac'), (v.get('roofline') or {}).get('traffic'), (v.get('roofline_prefill') or {}).get('achieved')) for k, v in d.get('extra_configs', {}).items()]";;
 *) echo "unknown step $w";;
 esac
 done

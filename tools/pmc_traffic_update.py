@@ -1,0 +1,44 @@
+"""Fold one rocprofv3 PMC pass of the decode-attention replay into profiles/pmc_traffic.json.
+
+    python tools/pmc_traffic_update.py <pmc_summary.json> <replay_under_pmc.json> <model> "<kernel label>"
+
+<pmc_summary.json>   : tools/pmc_summary.py output of `rocprofv3 --pmc FETCH_SIZE --kernel-include-regex decode_ --
+                       python tools/attn_replay.py --fused --reps 1 [--hq .. --hkv .. --layers ..]`
+<replay_under_pmc.json>: the JSON line that replay printed (algorithmic_bytes_per_launch of the same launches)
+Entry written: kernels[<kernel label>] = {hbm_read_bytes_over_algorithmic, ...}. FETCH_SIZE is in KiB and, on gfx950,
+counts HALF the bytes of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM section): doubled here.
+bench.py multiplies a run's algorithmic bytes per launch by this ratio for `roofline.traffic`.
+"""
+import json
+import os
+import sys
+
+summary, replay, model, label = sys.argv[1:5]
+rows = json.load(open(summary))
+rep = json.loads([ln for ln in open(replay).read().splitlines() if ln.startswith("{")][-1])
+fetch = {r["kernel"].split("<")[0].split("::")[-1]: r for r in rows if r["counter"] == "FETCH_SIZE"}
+main = next(v for k, v in fetch.items() if k.startswith("decode_") and "combine" not in k and "plan" not in k)
+comb = next((v for k, v in fetch.items() if "combine" in k), None)
+per_launch_kib = main["mean"] + (comb["mean"] if comb else 0.0)
+hbm = per_launch_kib * 1024 * 2
+alg = rep["algorithmic_bytes_per_launch"]
+path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
+try:
+    db = json.load(open(path))
+except OSError:
+    db = {}
+if "kernels" not in db:                         # round-2 layout: one entry at the top level
+    old = dict(db)
+    db = {"kernels": {}}
+    if "kernel_name" in old:
+        db["kernels"][old["kernel_name"]] = old
+db["kernels"][label] = {
+    "source": f"{os.path.basename(summary)} (rocprofv3 --pmc FETCH_SIZE --kernel-include-regex decode_ -- python "
+              f"tools/attn_replay.py --fused --reps 1 ...)",
+    "model": model, "dispatches": main["dispatches"],
+    "FETCH_SIZE_mean_KiB": {"main": main["mean"], "decode_stream_combine_kernel": comb["mean"] if comb else None},
+    "correction": "x2: on gfx950 FETCH_SIZE reports half the bytes of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM section)",
+    "hbm_read_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "hbm_read_bytes_over_algorithmic": hbm / alg,
+}
+json.dump(db, open(path, "w"), indent=1)
+print(label, "traffic / algorithmic =", round(hbm / alg, 4))
