@@ -120,10 +120,17 @@ int nvl_linear_decode(const void* x, const void* weight, void* out,
  *     nvl_add_rmsnorm_splitk); *workspace_bytes = scratch the call needs for modes 0 / 1 when
  *     the plan splits K (0 otherwise).
  *   nvl_linear_wide: NVL_EUNSUPPORTED when the plan query says 0. k % 128 == 0, n % 16 == 0
- *     (mode 1: n % 32 == 0). */
+ *     (mode 1: n % 32 == 0). weight_layout 0: `weight` is the reference's row-major [n, k]
+ *     parameter; 1: the tile-packed copy nvl_pack_weight_tiles made of it (what the engine
+ *     passes: every wave load of the weight stream is then one contiguous KiB).
+ *   nvl_pack_weight_tiles: packed[n/16][k/32][64][8] <- weight[n][k] (bf16, n % 16 == 0,
+ *     k % 32 == 0): the 16 x 32 sub-matrix of (tile t, k-block b) is stored as the 64 lanes x
+ *     8 elements of the v_mfma_f32_16x16x32_bf16 A operand (lane = 16 * (k % 32 / 8) + row % 16).
+ *     Done once at model-load time (utils/loader.py:12-28 fills the row-major parameter). */
 int nvl_linear_wide_plan(int64_t m, int n, int k, int mode, int* splits, size_t* workspace_bytes);
 int nvl_linear_wide(const void* x, const void* weight, void* out, int64_t m, int n, int k, int mode,
-                    void* workspace, size_t workspace_bytes, void* stream);
+                    int weight_layout, void* workspace, size_t workspace_bytes, void* stream);
+int nvl_pack_weight_tiles(const void* weight, void* packed, int64_t n, int64_t k, void* stream);
 
 /* Fused split-K reduction + residual add + RMSNorm: replaces
  * RMSNorm.add_rms_forward (layers/layernorm.py:28-40) when its input is the

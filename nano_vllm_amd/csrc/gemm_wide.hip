@@ -38,6 +38,14 @@
 //   * v_mfma_f32_16x16x32_bf16, A = W fragment, B = x fragment: lane (l15 = lane & 15, lq = lane >> 4) ends up with
 //     out[row = 16 mt + l15][col = tile + 4 lq .. + 3] => 8-byte bf16 / 16-byte fp32 stores.
 //   * SiLU: a wave's two tiles are a gate tile and the matching up tile, paired in registers.
+//   * PACKED weights (round 3, the default the engine uses): a fragment-shaped load of a ROW-MAJOR matrix makes every
+//     16-lane group of the wave touch 16 different 128-byte lines (16 rows x 16 B), and the CU's address / L1 path
+//     retires such a group at ~1 line per clock: 15 B/clk/CU measured (tools/probes/l2_read_probe.hip) against 45-60
+//     for row-contiguous loads — which is why the weight and the x terms of the time model above ADD: together they
+//     saturate that path. nvl_pack_weight_tiles stores W once, at model-load time, in the consumer waves' fragment
+//     order — [N/16 tiles][K/32 k-blocks][64 lanes][8 elements]: the 16 x 32 sub-matrix of a (tile, k-block) is ONE
+//     contiguous KiB in lane order, a wave's whole K walk over a tile one contiguous run — so a wave instruction reads
+//     1 KiB contiguous (each 16-lane group 2 lines) and the weight stream costs a quarter of the address-path time.
 // Rounding points are the reference's: the GEMM output is rounded to bf16 before the activation.
 #include "common.h"
 #include <stdlib.h>
@@ -51,7 +59,7 @@ enum { EPI_BF16 = 0, EPI_SILU = 1, EPI_PARTIAL = 2 };
 
 __device__ __forceinline__ float silu_f32(float g) { return g / (1.f + __expf(-g)); }
 
-template <int MT, int NT, int NW, int EPI, int RING>
+template <int MT, int NT, int NW, int EPI, int RING, bool PACKED>
 __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
                                                                      const bf16_t* __restrict__ w,
                                                                      void* __restrict__ out, int M, int N, int K,
@@ -134,13 +142,25 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
   // ---- consumer waves ----------------------------------------------------------------------------------------------
   // first output column of this wave's tiles, and the W rows feeding them (SiLU: tile 0 = gate, tile 1 = up)
   const int n0 = (blockIdx.x * NW + wave) * (GT * 16);
+  // element strides of this wave's weight pointer per k step / per 32-wide k block: row-major rows advance by k;
+  // packed tiles advance by whole KiB blocks (512 elements) of the tile's contiguous run
+  constexpr int kWStep = PACKED ? kKB * 512 : kBK;
+  constexpr int kWBlk = PACKED ? 512 : 32;
   const bf16_t* wrow[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    int row = n0 + (nt % GT) * 16 + l15;
-    row = row < out_cols ? row : out_cols - 1;                    // ragged last workgroup: any valid row, masked below
-    if (EPI == EPI_SILU && nt >= GT) row += out_cols;
-    wrow[nt] = w + (int64_t)row * K + k0 + lq * 8;
+    if constexpr (PACKED) {
+      int tile = (n0 >> 4) + (nt % GT);
+      const int ntiles = out_cols >> 4;
+      tile = tile < ntiles ? tile : ntiles - 1;                   // ragged last workgroup: any valid tile, masked below
+      if (EPI == EPI_SILU && nt >= GT) tile += ntiles;
+      wrow[nt] = w + (int64_t)tile * 16 * K + (k0 >> 5) * 512 + lane * 8;
+    } else {
+      int row = n0 + (nt % GT) * 16 + l15;
+      row = row < out_cols ? row : out_cols - 1;                  // ragged last workgroup: any valid row, masked below
+      if (EPI == EPI_SILU && nt >= GT) row += out_cols;
+      wrow[nt] = w + (int64_t)row * K + k0 + lq * 8;
+    }
   }
   int frag_off[kKB];                                              // B fragment of k block kb: row l15 of a row tile
 #pragma unroll
@@ -159,7 +179,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int kb = 0; kb < kKB; ++kb)
-        dst[nt][kb] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[nt] + s * kBK + kb * 32));
+        dst[nt][kb] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[nt] + s * kWStep + kb * kWBlk));
   };
 
   // one k step: the MFMAs of every row tile against the weight set `wfs`, x fragments from LDS stage `xs`; when
@@ -195,7 +215,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
         for (int j = 0; j < L; ++j)
           if (j >= j0 && j < j1)
             wdst[j / kKB][j % kKB] = __builtin_nontemporal_load(
-                reinterpret_cast<const u32x4_t*>(wrow[j / kKB] + ks * kBK + (j % kKB) * 32));
+                reinterpret_cast<const u32x4_t*>(wrow[j / kKB] + ks * kWStep + (j % kKB) * kWBlk));
       }
       if (g + 1 < NG) fread(g + 1, f[(g + 1) & 1]);
 #pragma unroll
@@ -300,6 +320,21 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
   *reinterpret_cast<u32x2_t*>(out + (int64_t)row * out_cols + c) = ov;
 }
 
+// W [N, K] row-major -> packed [N/16][K/32][64 lanes][8]: thread = one 16-byte chunk of the destination.
+__global__ __launch_bounds__(256) void pack_weight_tiles_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ packed,
+                                                                 int64_t chunks, int K) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= chunks) return;
+  const int lane = (int)(c & 63);
+  const int64_t blk = c >> 6;                                     // (tile, k-block)
+  const int kblocks = K >> 5;
+  const int64_t tile = blk / kblocks;
+  const int kb = (int)(blk - tile * kblocks);
+  const int64_t row = tile * 16 + (lane & 15);
+  const int k = kb * 32 + (lane >> 4) * 8;
+  *reinterpret_cast<u32x4_t*>(packed + c * 8) = *reinterpret_cast<const u32x4_t*>(w + row * K + k);
+}
+
 // ---- host: plan ---------------------------------------------------------------------------------------------------
 struct WidePlan {
   int mt, nt, nw, mgroups, tiles, split, steps;   // tiles = workgroups along N; steps = 128-wide k steps per workgroup
@@ -397,23 +432,31 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
   return best_t < 1e30;
 }
 
-template <int MT, int NT, int NW, int EPI>
-int launch_wide(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
+template <int MT, int NT, int NW, int EPI, bool PACKED>
+int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
   constexpr int RING = ring_of(NT, NW, MT);
   const size_t lds = (size_t)3 * MT * 16 * 256;
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wide_kernel<MT, NT, NW, EPI, RING>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       nvl_set_error("nvl_linear_wide: cannot reserve %zu B of LDS", lds);
       return NVL_ELAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING>), dim3(p.tiles, p.split, p.mgroups), dim3((NW + 1) * 64), lds,
-                     s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps);
+  hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>), dim3(p.tiles, p.split, p.mgroups),
+                     dim3((NW + 1) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps);
   return NVL_OK;
+}
+
+thread_local bool g_packed = false;      // weight layout of the launch being dispatched (set by nvl_linear_wide)
+
+template <int MT, int NT, int NW, int EPI>
+int launch_wide(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
+  return g_packed ? launch_wide_l<MT, NT, NW, EPI, true>(p, x, w, out, m, n, k, s)
+                  : launch_wide_l<MT, NT, NW, EPI, false>(p, x, w, out, m, n, k, s);
 }
 
 template <int NT, int NW, int EPI>
@@ -451,10 +494,24 @@ extern "C" int nvl_linear_wide_plan(int64_t m, int n, int k, int mode, int* spli
   return 1;
 }
 
+extern "C" int nvl_pack_weight_tiles(const void* weight, void* packed, int64_t n, int64_t k, void* stream) {
+  NVL_REQUIRE(weight && packed && weight != packed, "nvl_pack_weight_tiles: null or aliased pointers");
+  NVL_REQUIRE(n > 0 && k > 0 && n % 16 == 0 && k % 32 == 0 && k < (1ll << 31), "nvl_pack_weight_tiles: n=%lld must be a multiple of 16, k=%lld of 32",
+              (long long)n, (long long)k);
+  NVL_REQUIRE(((uintptr_t)weight | (uintptr_t)packed) % 16 == 0, "nvl_pack_weight_tiles: pointers must be 16-byte aligned");
+  const int64_t chunks = n * k / 8;
+  NVL_REQUIRE((chunks + 255) / 256 < (1ll << 31), "nvl_pack_weight_tiles: matrix too large");
+  hipLaunchKernelGGL(pack_weight_tiles_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)weight, (bf16_t*)packed, chunks, (int)k);
+  return nvl_check_launch("nvl_pack_weight_tiles");
+}
+
 extern "C" int nvl_linear_wide(const void* x, const void* weight, void* out, int64_t m, int n, int k, int mode,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+                               int weight_layout, void* workspace, size_t workspace_bytes, void* stream) {
   NVL_REQUIRE(x && weight && out, "nvl_linear_wide: null pointer");
   NVL_REQUIRE(mode >= 0 && mode <= 2, "nvl_linear_wide: mode=%d (0 bf16, 1 silu*mul, 2 split-K fp32 partials)", mode);
+  NVL_REQUIRE(weight_layout == 0 || weight_layout == 1, "nvl_linear_wide: weight_layout=%d (0 row-major [N, K], 1 tile-packed)", weight_layout);
+  g_packed = weight_layout == 1;
   NVL_REQUIRE(((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)workspace) % 16 == 0,
               "nvl_linear_wide: pointers must be 16-byte aligned");
   WidePlan p;

@@ -287,6 +287,20 @@ class LinearBase(nn.Module):
             self.bias.weight_loader = self.weight_loader
         else:
             self.register_parameter("bias", None)
+        self.weight_packed: torch.Tensor | None = None     # tile-packed copy for nvl_linear_wide (pack_for_decode)
+
+    def pack_for_decode(self) -> int:
+        """After the weights are loaded: keep a tile-packed copy (ops.pack_weight_tiles) of a projection whose decode
+        GEMM is nvl_linear_wide's — deep reductions the skinny kernel does not cover (Qwen3-8B / 32B shapes). The
+        row-major parameter stays: prefill-sized GEMMs run on hipBLASLt from it. Returns the extra bytes.
+        NVL_WIDE_PACKED=0 keeps the row-major weight stream (A/B measurements)."""
+        n, k = self.weight.shape
+        if (self.bias is not None or not self.weight.is_cuda or n % 16 or k % 128
+                or os.environ.get("NVL_WIDE_PACKED", "1") == "0" or os.environ.get("NVL_GEMM_WIDE", "auto") == "0"
+                or ops.linear_decode_splits(144, n, k, ops.LINEAR_BF16) or ops.linear_wide_plan(144, n, k, ops.LINEAR_BF16) is None):
+            return 0
+        self.weight_packed = ops.pack_weight_tiles(self.weight.data)
+        return self.weight_packed.numel() * 2
 
     def _my_slice(self, loaded: torch.Tensor, dim: int) -> torch.Tensor:
         size = loaded.shape[dim] // self.tp_size
@@ -297,7 +311,7 @@ class LinearBase(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if self.bias is None and _decode_sized(x):
-            y = decode_linear(x, self.weight, ops.LINEAR_BF16)
+            y = decode_linear(x, self.weight, ops.LINEAR_BF16, packed=self.weight_packed)
             if y is not None:
                 return y
         return F.linear(x, self.weight, self.bias)
@@ -366,10 +380,10 @@ def wide_choices() -> dict:
     return dict(_wide_choice)
 
 
-def _use_wide(x: torch.Tensor, weight: torch.Tensor, mode: int) -> bool:
+def _use_wide(x: torch.Tensor, weight: torch.Tensor, mode: int, packed: torch.Tensor | None = None) -> bool:
     m, k = x.shape
     n = weight.shape[0]
-    key = (m, n, k, mode, x.device.index)
+    key = (m, n, k, mode, x.device.index, packed is not None)
     c = _wide_choice.get(key)
     if c is not None:
         return c
@@ -384,8 +398,9 @@ def _use_wide(x: torch.Tensor, weight: torch.Tensor, mode: int) -> bool:
     else:
         splits, ws_bytes = plan
         ws = _scratch(ws_bytes, x.device)
-        out = ops.linear_wide(x, weight, mode, workspace=ws)
-        t_wide = _time_cold(lambda: ops.linear_wide(x, weight, mode, out=out, workspace=ws), x.device)
+        wsrc, pk = (packed, True) if packed is not None else (weight, False)
+        out = ops.linear_wide(x, wsrc, mode, workspace=ws, packed=pk)
+        t_wide = _time_cold(lambda: ops.linear_wide(x, wsrc, mode, out=out, workspace=ws, packed=pk), x.device)
         if mode == ops.LINEAR_SILU:
             t_lib = _time_cold(lambda: ops.silu_mul(F.linear(x, weight)), x.device)
         else:
@@ -397,15 +412,19 @@ def _use_wide(x: torch.Tensor, weight: torch.Tensor, mode: int) -> bool:
     return c
 
 
-def decode_linear(x: torch.Tensor, weight: torch.Tensor, mode: int, out: torch.Tensor | None = None):
+def decode_linear(x: torch.Tensor, weight: torch.Tensor, mode: int, out: torch.Tensor | None = None,
+                  packed: torch.Tensor | None = None):
     """x [M, K] . weight[N, K]^T on a hand-written decode GEMM, or None when neither kernel takes the shape (the
-    caller keeps the library GEMM). mode as in ops.linear_decode."""
+    caller keeps the library GEMM). mode as in ops.linear_decode. `packed`: the module's tile-packed copy of
+    `weight` (LinearBase.pack_for_decode), streamed by the wide kernel instead of the row-major parameter."""
     m, k = x.shape
     n = weight.shape[0]
     if ops.linear_decode_splits(m, n, k, mode):
         return ops.linear_decode(x, weight, mode, out=out)
-    if _use_wide(x, weight, mode):
+    if _use_wide(x, weight, mode, packed):
         plan = ops.linear_wide_plan(m, n, k, mode)
+        if packed is not None:
+            return ops.linear_wide(x, packed, mode, out=out, workspace=_scratch(plan[1], x.device), packed=True)
         return ops.linear_wide(x, weight, mode, out=out, workspace=_scratch(plan[1], x.device))
     return None
 
@@ -447,7 +466,7 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
         epilogue (one launch, no [N, 2*inter] round trip)."""
         if (self.bias is None and len(self.output_sizes) == 2 and self.output_sizes[0] == self.output_sizes[1]
                 and _decode_sized(x)):
-            y = decode_linear(x, self.weight, ops.LINEAR_SILU)
+            y = decode_linear(x, self.weight, ops.LINEAR_SILU, packed=self.weight_packed)
             if y is not None:
                 return y
         return ops.silu_mul(self.forward(x))
@@ -504,7 +523,7 @@ class RowParallelLinear(LinearBase):
         n, k = self.weight.shape
         if self.tp_size == 1:
             if self.bias is None and _decode_sized(x):
-                y = decode_linear(x, self.weight, ops.LINEAR_PARTIAL)
+                y = decode_linear(x, self.weight, ops.LINEAR_PARTIAL, packed=self.weight_packed)
                 if y is not None:
                     return y
             return self.forward(x)
@@ -513,7 +532,7 @@ class RowParallelLinear(LinearBase):
             # the GEMM writes its partial sums straight into this rank's shared comm region: the all-reduce kernel
             # then starts at its first flag instead of a copy-in phase
             buf = c.input_buffer(x.shape[0], n, x.device)
-            if not _decode_sized(x) or decode_linear(x, self.weight, ops.LINEAR_BF16, out=buf) is None:
+            if not _decode_sized(x) or decode_linear(x, self.weight, ops.LINEAR_BF16, out=buf, packed=self.weight_packed) is None:
                 torch.mm(x, self.weight.t(), out=buf)
             return PartialSum(buf)
         return self.forward(x)

@@ -29,8 +29,9 @@ SIGNATURES = {
     "nvl_linear_decode_splits": (c_int, [c_int64, c_int, c_int, c_int]),
     "nvl_linear_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "nvl_linear_wide_plan": (c_int, [c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "nvl_linear_wide": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_size_t,
+    "nvl_linear_wide": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                 c_void_p]),
+    "nvl_pack_weight_tiles": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "nvl_add_rmsnorm_splitk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "nvl_silu_mul": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "nvl_rope_neox": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p]),
@@ -230,10 +231,22 @@ def linear_wide_plan(m: int, n: int, k: int, mode: int) -> tuple[int, int] | Non
     return _wide_cache[key]
 
 
+def pack_weight_tiles(weight: torch.Tensor) -> torch.Tensor:
+    """Tile-packed copy of a row-major [N, K] bf16 weight (nvl_pack_weight_tiles): same shape and bytes, stored as
+    [N/16][K/32][64 lanes][8] so that every wave load of nvl_linear_wide's weight stream is one contiguous KiB."""
+    _dev(weight, "weight")
+    assert weight.dim() == 2 and weight.is_contiguous() and weight.dtype == torch.bfloat16
+    n, k = weight.shape
+    packed = torch.empty_like(weight)
+    _check(lib().nvl_pack_weight_tiles(weight.data_ptr(), packed.data_ptr(), n, k, _stream()))
+    return packed
+
+
 def linear_wide(x: torch.Tensor, weight: torch.Tensor, mode: int = LINEAR_BF16, out: torch.Tensor | None = None,
-                workspace: torch.Tensor | None = None) -> torch.Tensor:
+                workspace: torch.Tensor | None = None, packed: bool = False) -> torch.Tensor:
     """Deep-K decode linear (same modes as linear_decode). `workspace`: uint8 scratch of the plan's size for
-    modes 0 / 1 when the plan splits K (allocated here when omitted)."""
+    modes 0 / 1 when the plan splits K (allocated here when omitted). `packed`: `weight` is the pack_weight_tiles()
+    copy of the [N, K] parameter (same shape)."""
     _dev(x, "x")
     assert x.dim() == 2 and x.is_contiguous() and weight.is_contiguous()
     assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
@@ -252,7 +265,7 @@ def linear_wide(x: torch.Tensor, weight: torch.Tensor, mode: int = LINEAR_BF16, 
     if ws_bytes and workspace is None:
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
     assert not ws_bytes or workspace.numel() * workspace.element_size() >= ws_bytes
-    _check(lib().nvl_linear_wide(x.data_ptr(), weight.data_ptr(), out.data_ptr(), m, n, k, mode,
+    _check(lib().nvl_linear_wide(x.data_ptr(), weight.data_ptr(), out.data_ptr(), m, n, k, mode, 1 if packed else 0,
                                  workspace.data_ptr() if ws_bytes else None, ws_bytes, _stream()))
     return out
 

@@ -78,8 +78,10 @@ def test_host_side_argument_validation_without_gpu():
     assert sp.value >= 1 and ws.value == (sp.value * 144 * 6144 * 4 if sp.value > 1 else 0)
     assert lib.nvl_linear_wide_plan(144, 4096, 4096, 2, ctypes.byref(sp), ctypes.byref(ws)) == 1 and ws.value == 0
     assert lib.nvl_linear_wide_plan(144, 6144, 1000, 0, None, None) == 0
-    assert lib.nvl_linear_wide(16, 16, 16, 144, 6144, 1000, 0, None, 0, None) == -3 and b"not covered" in lib.nvl_last_error()
-    assert lib.nvl_linear_wide(None, 16, 16, 144, 6144, 4096, 0, None, 0, None) == -1
+    assert lib.nvl_linear_wide(16, 16, 16, 144, 6144, 1000, 0, 0, None, 0, None) == -3 and b"not covered" in lib.nvl_last_error()
+    assert lib.nvl_linear_wide(None, 16, 16, 144, 6144, 4096, 0, 0, None, 0, None) == -1
+    assert lib.nvl_linear_wide(16, 16, 16, 144, 6144, 4096, 0, 7, None, 0, None) == -1 and b"weight_layout" in lib.nvl_last_error()
+    assert lib.nvl_pack_weight_tiles(16, 32, 24, 64, None) == -1 and b"multiple of 16" in lib.nvl_last_error()
 
 
 def test_linear_wide_plan_covers_the_model_shapes_on_the_host():

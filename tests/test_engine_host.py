@@ -291,7 +291,8 @@ def test_decode_gemm_chooser_policies(monkeypatch):
     monkeypatch.setattr(ops, "linear_decode_splits", lambda m, n, k, mode: 1 if k <= 1024 else 0)
     monkeypatch.setattr(ops, "linear_decode", lambda x, w, mode, out=None: calls.append("skinny") or "skinny")
     monkeypatch.setattr(ops, "linear_wide_plan", lambda m, n, k, mode: calls.append("plan") or ((2, 64) if n != 48 else None))
-    monkeypatch.setattr(ops, "linear_wide", lambda x, w, mode, out=None, workspace=None: calls.append("wide") or "wide")
+    monkeypatch.setattr(ops, "linear_wide", lambda x, w, mode, out=None, workspace=None, packed=False:
+                        calls.append("wide-packed" if packed else "wide") or "wide")
     monkeypatch.setattr(layers, "_scratch", lambda nbytes, device: None)
     monkeypatch.setattr(layers, "_wide_choice", {})
     x, shallow, deep, uncovered = torch.zeros(16, 1024), torch.zeros(64, 1024), torch.zeros(64, 4096), torch.zeros(48, 4096)
@@ -305,9 +306,11 @@ def test_decode_gemm_chooser_policies(monkeypatch):
     monkeypatch.setenv("NVL_GEMM_WIDE", "1")
     assert layers.decode_linear(xd, deep, ops.LINEAR_SILU) == "wide"
     assert layers.decode_linear(xd, uncovered, ops.LINEAR_BF16) is None                     # plan says no
-    assert layers.wide_choices()[(16, 64, 4096, ops.LINEAR_SILU, None)] is True
+    assert layers.wide_choices()[(16, 64, 4096, ops.LINEAR_SILU, None, False)] is True
     calls.clear()
     assert layers.decode_linear(xd, deep, ops.LINEAR_SILU) == "wide" and calls == ["plan", "wide"]   # decision cached
+    calls.clear()                 # a module with a tile-packed copy streams THAT (its own cached decision)
+    assert layers.decode_linear(xd, deep, ops.LINEAR_SILU, packed=deep.clone()) == "wide" and calls[-1] == "wide-packed"
     # auto: timed outside a capture, deferred (not cached) inside one
     layers._wide_choice.clear()
     monkeypatch.setenv("NVL_GEMM_WIDE", "auto")
@@ -319,7 +322,8 @@ def test_decode_gemm_chooser_policies(monkeypatch):
     assert layers.decode_linear(xd, deep, ops.LINEAR_BF16) == "wide"
     times = iter([2.0, 1.0])
     assert layers.decode_linear(xd, deep, ops.LINEAR_SILU) is None                          # library GEMM is faster
-    assert layers.wide_choices() == {(16, 64, 4096, ops.LINEAR_BF16, None): True, (16, 64, 4096, ops.LINEAR_SILU, None): False}
+    assert layers.wide_choices() == {(16, 64, 4096, ops.LINEAR_BF16, None, False): True,
+                                     (16, 64, 4096, ops.LINEAR_SILU, None, False): False}
 
 
 # ---------------------------------------------------------------------------------------------------------------

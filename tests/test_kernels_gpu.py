@@ -172,6 +172,8 @@ def test_linear_wide_bf16(ops, m, n, k):
     y = ops.linear_wide(dev(x), dev(w), ops.LINEAR_BF16)
     assert y.shape == (m, n) and _close_to_rounded(y, acc, atol=1e-4)
     assert float((ref.bf16_ulp_diff(y.cpu(), acc.to(BF16)) > 0).float().mean()) < 0.02   # order-of-summation flips only
+    # the tile-packed weight copy (what the engine streams): other addresses, the same arithmetic in the same order
+    assert torch.equal(ops.linear_wide(dev(x), ops.pack_weight_tiles(dev(w)), ops.LINEAR_BF16, packed=True), y)
 
 
 @pytest.mark.parametrize("m", [1, 16, 144, 256])
@@ -186,6 +188,17 @@ def test_linear_wide_silu(ops, m, n, k):
     d = (y.cpu().float() - want.float()).abs()
     assert float(d.max()) <= 2e-2 * float(want.float().abs().max())
     assert float((ref.bf16_ulp_diff(y.cpu(), want) > 1).float().mean()) < 0.02
+    assert torch.equal(ops.linear_wide(dev(x), ops.pack_weight_tiles(dev(w)), ops.LINEAR_SILU, packed=True), y)
+
+
+def test_pack_weight_tiles_layout(ops):
+    """packed[n/16][k/32][64 lanes][8] holds the 16 x 32 sub-matrix of (tile, k-block) in v_mfma_f32_16x16x32_bf16
+    A-operand lane order: lane = 16 * (k % 32 // 8) + row % 16."""
+    n, k = 96, 256
+    w = torch.arange(n * k, dtype=torch.float32).remainder(30011).to(BF16).view(n, k)
+    got = ops.pack_weight_tiles(dev(w)).cpu()
+    want = w.view(n // 16, 16, k // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(n, k)
+    assert torch.equal(got, want)
 
 
 @pytest.mark.parametrize("m", [1, 16, 131, 144, 256])
@@ -197,6 +210,7 @@ def test_linear_wide_partials_into_add_rmsnorm(ops, m, n, k):
     assert splits >= 1 and ws == 0
     parts = ops.linear_wide(dev(x), dev(w), ops.LINEAR_PARTIAL)
     assert parts.shape == (splits, m, n) and parts.dtype == torch.float32
+    assert torch.equal(ops.linear_wide(dev(x), ops.pack_weight_tiles(dev(w)), ops.LINEAR_PARTIAL, packed=True), parts)
     s = parts.sum(0).cpu()
     assert float((s - acc).abs().max()) <= 1e-4 * float(acc.abs().max()) + 1e-5
     r = (torch.randn(m, n, generator=g(36)) * 2).to(BF16)

@@ -1,6 +1,7 @@
 """Wide-tile deep-K decode linear (nvl_linear_wide): correctness vs an fp32 reference + time vs hipBLASLt.
 usage: python tools/gemm_wide_bench.py [model ...]   (8b 32b 32b_tp4 32b_tp8 lm_head; default 8b 32b_tp8)
-Prints one JSON line: time_us[shape] = [ours_us, blas_us, ours_GBps, splits]."""
+Prints one JSON line: time_us[shape] = [ours_us (tile-packed weights), blas_us, ours_GBps, splits, ours_us with the
+row-major weight stream]."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -68,23 +69,30 @@ def main():
                     res["relerr"][f"{model}_{name}_m{m}"] = round(check(m, n, k, mode), 5)
             for m in ms:
                 plan = ops.linear_wide_plan(m, n, k, mode)
-                ncopy = max(2, min(12, int(1.2e9 // (n * k * 2))))
+                ncopy = max(2, min(12, int(0.8e9 // (n * k * 2))))
                 ws = [(torch.randn(n, k, device="cuda") * 0.05).to(BF16) for _ in range(ncopy)]
                 x = torch.randn(m, k, device="cuda").to(BF16)
-                t_ours = float("nan")
+                t_ours = t_rowmajor = float("nan")
                 if plan:
                     out = ops.linear_wide(x, ws[0], mode)
                     scratch = torch.empty(max(plan[1], 16), dtype=torch.uint8, device="cuda")
                     def ours():
                         for w in ws:
                             ops.linear_wide(x, w, mode, out=out, workspace=scratch)
-                    t_ours = graph_time(ours) / len(ws)
+                    t_rowmajor = graph_time(ours) / len(ws)
+                    pk = [ops.pack_weight_tiles(w) for w in ws]
+                    def ours_packed():
+                        for w in pk:
+                            ops.linear_wide(x, w, mode, out=out, workspace=scratch, packed=True)
+                    t_ours = graph_time(ours_packed) / len(ws)
+                    del pk
                 def blas():
                     for w in ws:
                         F.linear(x, w)
                 t_blas = graph_time(blas) / len(ws)
                 res["time_us"][f"{model}_{name}_m{m}"] = [round(t_ours, 2), round(t_blas, 2),
-                                                          round(n * k * 2 / t_ours / 1e3, 1), plan[0] if plan else 0]
+                                                          round(n * k * 2 / t_ours / 1e3, 1), plan[0] if plan else 0,
+                                                          round(t_rowmajor, 2)]
                 del ws
     res["relerr_max"] = max(res["relerr"].values()) if res["relerr"] else None
     print(json.dumps(res))

@@ -16,8 +16,10 @@ import sys
 summary, replay, model, label = sys.argv[1:5]
 rows = json.load(open(summary))
 rep = json.loads([ln for ln in open(replay).read().splitlines() if ln.startswith("{")][-1])
-fetch = {r["kernel"].split("<")[0].split("::")[-1]: r for r in rows if r["counter"] == "FETCH_SIZE"}
-main = next(v for k, v in fetch.items() if k.startswith("decode_") and "combine" not in k and "plan" not in k)
+fetch = {r["kernel"]: r for r in rows if r["counter"] == "FETCH_SIZE"}
+# (template instantiations show up with truncated mangled names: the attention kernel is the row that is neither the
+# split merge nor the per-step plan — and by far the largest)
+main = max((v for k, v in fetch.items() if "combine" not in k and "plan" not in k), key=lambda v: v["mean"])
 comb = next((v for k, v in fetch.items() if "combine" in k), None)
 per_launch_kib = main["mean"] + (comb["mean"] if comb else 0.0)
 hbm = per_launch_kib * 1024 * 2
