@@ -297,7 +297,15 @@ int nvl_sample(const void* logits, int64_t logits_row_stride,
                const float* temperatures, int64_t* out,
                int64_t batch, int64_t vocab,
                uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+               const uint64_t* row_keys,
                void* workspace, size_t workspace_bytes, void* stream);
+/* `row_keys` (nvl_sample, nvl_sample_shard, nvl_lmhead_sample; optional, may be NULL): device
+ * uint64 [batch]. With it, row r of the batch draws as "row" = low 32 bits of row_keys[r] at
+ * offset + (row_keys[r] >> 32) instead of as batch row r: a caller that passes
+ * sequence_id | position << 32 gets draws that depend on (seed, sequence, position, column)
+ * only — not on the sequence's row in the batch or on what else is being decoded (the
+ * reference's torch generator is consumed in batch order, layers/sampler.py:11: there the
+ * tokens of a request change with its neighbours). */
 
 /* Vocab-parallel form of the sampler (the reference gathers every rank's [batch, vocab/tp]
  * logits on rank 0, layers/embed_head.py:62-65, and samples there; here each rank reduces ITS
@@ -313,6 +321,7 @@ int nvl_sample_shard(const void* logits, int64_t logits_row_stride,
                      const float* temperatures, void* best_packed,
                      int64_t batch, int64_t vocab_local, int64_t col_offset,
                      uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                     const uint64_t* row_keys,
                      void* workspace, size_t workspace_bytes, void* stream);
 int nvl_sample_merge(const void* best_packed, int parts, int64_t part_stride_bytes,
                      int64_t* out, int64_t batch, void* stream);
@@ -334,6 +343,7 @@ size_t nvl_lmhead_sample_workspace_bytes(int64_t batch, int64_t vocab_local, int
 int nvl_lmhead_sample(const void* x, const void* weight, const float* temperatures, int64_t* out,
                       void* best_packed, void* logits_out, int64_t batch, int64_t vocab_local, int k,
                       int64_t col_offset, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                      const uint64_t* row_keys,
                       void* workspace, size_t workspace_bytes, void* stream);
 
 /* Feed the previous step's sampled ids back as this step's input ids ON THE DEVICE:

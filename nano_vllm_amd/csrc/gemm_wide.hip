@@ -360,23 +360,26 @@ int round_mt(int mtiles, int nt) {
   return 0;
 }
 
-// Model of one launch (us) for a candidate decomposition. A CU streams ~20 GB/s of weights however much it keeps in
-// flight, so time ~ (rounds of 256 workgroups) x (steps per workgroup) x (time of a step on one CU), where a step is
-// bound by its weight bytes at that rate, by its MFMAs (one wave per SIMD) or by staging x (L2 -> LDS); plus the
-// pipeline fill per workgroup, the launch, and the slab traffic when K is split.
+// Model of one launch (us) for a candidate decomposition, fitted to a sweep of every (NT, NW, split) plan on the
+// Qwen3-8B / 32B / 32B-per-rank shapes at 144 rows with tile-packed weights (tools/gemm_wide_sweep.py,
+// profiles/r03_gemm_wide_sweep_m144.jsonl: mean |log error| 9 %, the plan it picks is within 3 % of the best measured
+// one on average). A CU streams ~28 GB/s of packed weights and ~67 GB/s of x tiles (L2 -> LDS); the two overlap, but
+// not perfectly (a quarter of the shorter one shows); time ~ (rounds of 256 workgroups) x (steps per workgroup) x
+// (time of a step on one CU) plus the pipeline fill per workgroup, the launch, and the slab traffic when K is split.
 double wide_cost(int64_t m, int n, int k, int mode, const WidePlan& p) {
   const int wgs = p.tiles * p.split * p.mgroups;
   const double rounds = (double)((wgs + 255) / 256);
   const double wbytes_step = (double)p.nw * p.nt * 16 * 256.0;
-  const double t_w = wbytes_step / 20.0e3;                                        // us at 20 GB/s per CU
+  const double t_w = wbytes_step / 28.0e3;                                        // us at 28 GB/s per CU
   const double t_mfma = (double)p.mt * p.nt * kKB * 16.0 / 2400.0;               // 16 clk per MFMA at 2.4 GHz
-  const double t_x = (double)p.mt * 16 * 256.0 / 100.0e3 + 0.15;                 // ~100 GB/s L2 -> LDS + barrier
+  const double t_x = (double)p.mt * 16 * 256.0 / 67.0e3;                          // L2 -> LDS staging of the x tile
   double t_step = t_w;
   if (t_mfma > t_step) t_step = t_mfma;
   if (t_x > t_step) t_step = t_x;
-  // the whole chip cannot exceed ~5 TB/s either
+  t_step += 0.25 * (t_w < t_x ? t_w : t_x) + 0.05;                                // imperfect overlap + the barrier
+  // the whole chip cannot exceed ~5.6 TB/s either
   const double active = wgs < 256 ? wgs : 256;
-  const double chip = active * wbytes_step / 5.0e6;
+  const double chip = active * wbytes_step / 5.6e6;
   if (chip > t_step) t_step = chip;
   double t = rounds * (p.steps * t_step + 2.0) + 2.5;
   if (p.split > 1 || mode == EPI_PARTIAL) {

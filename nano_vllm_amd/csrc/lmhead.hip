@@ -48,7 +48,7 @@ template <int MT, int NT, int SB>
 __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
     const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ temps,
     uint32_t* __restrict__ partial, bf16_t* __restrict__ logits_out, int M, int V, int K, int64_t col_offset,
-    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev) {
+    uint64_t seed, uint64_t offset, const uint64_t* __restrict__ offset_dev, const uint64_t* __restrict__ row_keys) {
   constexpr int kRows = MT * 16;
   constexpr int kCH = (kRows * 16 + kNW * 64 - 1) / (kNW * 64);   // 16-byte x chunks per thread per step
   // bytes per LDS stage: every thread writes its kCH chunks unconditionally (chunks past the last row land in the
@@ -170,13 +170,17 @@ __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
   }
 
   // ---- epilogue: bf16-round the logits, (optionally store them,) reduce each row's sampling key ---------------
-  const uint64_t off = offset + (offset_dev ? *offset_dev : 0ull);
+  const uint64_t off0 = offset + (offset_dev ? *offset_dev : 0ull);
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   Best* red = reinterpret_cast<Best*>(smem);                // [kNW][kRows] (the x stages are dead: barrier above)
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int m = mt * 16 + l15;
     const bool row_ok = m < M;
+    // the row's identity in the draw: the batch row, or (sequence, position) when the caller passes row keys
+    const uint64_t rk = (row_keys != nullptr && row_ok) ? row_keys[m] : (uint64_t)m;
+    const uint32_t rowid = (uint32_t)rk;
+    const uint64_t off = off0 + (rk >> 32);
     const float T = row_ok ? temps[m] : 0.f;
     const bool greedy = !(T > 0.f);
     const float invT = greedy ? 1.f : 1.f / T;
@@ -202,7 +206,7 @@ __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
         for (int r = 0; r < 4; ++r) key[r] = v[r];
       } else {
         const int64_t ctr = gcol0 >> 2;                      // the draw nvl_sample makes for these 4 columns
-        const Philox4 rnd = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32) ^ (uint32_t)(off << 8), (uint32_t)m,
+        const Philox4 rnd = philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32) ^ (uint32_t)(off << 8), rowid,
                                           (uint32_t)(off >> 24), k0, k1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -290,7 +294,7 @@ bool lm_plan(int64_t batch, int64_t vocab, int k, LmPlan* p) {
 template <int MT, int NT, int SB>
 int launch_lm(const LmPlan& p, const void* x, const void* w, const float* temps, uint32_t* partial, void* logits,
               int64_t batch, int64_t vocab, int k, int64_t col_offset, uint64_t seed, uint64_t offset,
-              const uint64_t* offset_dev, hipStream_t s) {
+              const uint64_t* offset_dev, const uint64_t* row_keys, hipStream_t s) {
   const size_t lds_x = (size_t)2 * ((MT * 16 * 16 + kNW * 64 - 1) / (kNW * 64)) * kNW * 64 * 16;
   const size_t lds_red = (size_t)kNW * MT * 16 * sizeof(Best);
   const size_t lds = lds_x > lds_red ? lds_x : lds_red;
@@ -306,7 +310,7 @@ int launch_lm(const LmPlan& p, const void* x, const void* w, const float* temps,
   }
   hipLaunchKernelGGL((lmhead_sample_kernel<MT, NT, SB>), dim3((unsigned)p.groups), dim3(kNW * 64), lds, s,
                      (const bf16_t*)x, (const bf16_t*)w, temps, partial, (bf16_t*)logits, (int)batch, (int)vocab, k,
-                     col_offset, seed, offset, offset_dev);
+                     col_offset, seed, offset, offset_dev, row_keys);
   return NVL_OK;
 }
 
@@ -321,7 +325,7 @@ extern "C" size_t nvl_lmhead_sample_workspace_bytes(int64_t batch, int64_t vocab
 extern "C" int nvl_lmhead_sample(const void* x, const void* weight, const float* temperatures, int64_t* out,
                                  void* best_packed, void* logits_out, int64_t batch, int64_t vocab_local, int k,
                                  int64_t col_offset, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+                                 const uint64_t* row_keys, void* workspace, size_t workspace_bytes, void* stream) {
   NVL_REQUIRE(x && weight && temperatures && workspace && (out || best_packed), "nvl_lmhead_sample: null pointer");
   NVL_REQUIRE(((uintptr_t)x | (uintptr_t)weight | (uintptr_t)workspace | (uintptr_t)logits_out | (uintptr_t)best_packed) % 8 == 0 &&
                   ((uintptr_t)x | (uintptr_t)weight) % 16 == 0,
@@ -342,7 +346,7 @@ extern "C" int nvl_lmhead_sample(const void* x, const void* weight, const float*
 #define NVL_LM_SB(MT_, NT_, SB_)                                                                                  \
   if (p.sb == SB_)                                                                                                \
     rc = launch_lm<MT_, NT_, SB_>(p, x, weight, temperatures, partial, logits_out, batch, vocab_local, k,         \
-                                  col_offset, seed, offset, offset_dev, s);
+                                  col_offset, seed, offset, offset_dev, row_keys, s);
 #define NVL_LM_CASE(MT_, NT_)                                                                                     \
   if (p.mt == MT_ && p.nt == NT_) { NVL_LM_SB(MT_, NT_, 8) NVL_LM_SB(MT_, NT_, 5) NVL_LM_SB(MT_, NT_, 3) }
   NVL_LM_CASE(1, 2) NVL_LM_CASE(2, 2) NVL_LM_CASE(3, 2) NVL_LM_CASE(5, 2) NVL_LM_CASE(7, 2) NVL_LM_CASE(9, 2)

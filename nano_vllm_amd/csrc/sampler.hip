@@ -5,6 +5,10 @@
 // so one streaming read of the bf16 logits (2 B/logit) replaces the reference's fp32 [B,V]
 // temporaries. E_i comes from Philox4x32-10 keyed by (seed; offset, row, column/4): the draw
 // does not depend on grid shape, so host code can replay it (nvl_sample_exponentials_host).
+// With `row_keys` (what the engine passes) the "row" of that key is not the batch row but the SEQUENCE:
+// row_keys[r] = sequence id | position << 32 -> the draw uses row = low word, offset + high word, i.e. it depends on
+// (seed, sequence, position, column) only — not on where the sequence sits in the batch, which step of the engine this
+// is, or what else is in flight (lookahead, preemption, other requests).
 // T == 0 selects plain argmax (lowest index wins ties), an extension the reference forbids
 // (sampling_params.py:11) but the parity harness needs.
 #include "common.h"
@@ -40,6 +44,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __res
                                                               const float* __restrict__ temps, int64_t vocab,
                                                               int64_t col_offset, uint64_t seed, uint64_t offset,
                                                               const uint64_t* __restrict__ offset_dev,
+                                                              const uint64_t* __restrict__ row_keys,
                                                               float* __restrict__ ws_val, int* __restrict__ ws_idx) {
   __shared__ float sv[4];
   __shared__ int si[4];
@@ -48,7 +53,9 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __res
   const float T = temps[row];
   const bool greedy = !(T > 0.f);
   const float invT = greedy ? 1.f : 1.f / T;
-  const uint64_t off = offset + (offset_dev ? *offset_dev : 0ull);
+  const uint64_t rk = row_keys ? row_keys[row] : (uint64_t)row;
+  const uint32_t rowid = (uint32_t)rk;
+  const uint64_t off = offset + (offset_dev ? *offset_dev : 0ull) + (rk >> 32);
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
   const bf16_t* lr = logits + row * row_stride;
   const int64_t nchunks = (vocab + 7) >> 3;
@@ -75,10 +82,10 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __res
 #pragma unroll
       for (int i = 0; i < 8; ++i) key[i] = f[i];
     } else {
-      const Philox4 r0 = philox4x32_10((uint32_t)(2 * gc), (uint32_t)((2 * gc) >> 32) ^ (uint32_t)(off << 8), (uint32_t)row,
+      const Philox4 r0 = philox4x32_10((uint32_t)(2 * gc), (uint32_t)((2 * gc) >> 32) ^ (uint32_t)(off << 8), rowid,
                                        (uint32_t)(off >> 24), k0, k1);
       const Philox4 r1 = philox4x32_10((uint32_t)(2 * gc + 1), (uint32_t)((2 * gc + 1) >> 32) ^ (uint32_t)(off << 8),
-                                       (uint32_t)row, (uint32_t)(off >> 24), k0, k1);
+                                       rowid, (uint32_t)(off >> 24), k0, k1);
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint32_t bits = i < 4 ? r0.v[i] : r1.v[i - 4];
@@ -156,7 +163,8 @@ extern "C" size_t nvl_sample_workspace_bytes(int64_t max_batch) {
 namespace {
 int sample_common(const void* logits, int64_t logits_row_stride, const float* temperatures, int64_t* out,
                   uint32_t* out_packed, int64_t batch, int64_t vocab, int64_t col_offset, uint64_t seed, uint64_t offset,
-                  const uint64_t* offset_dev, void* workspace, size_t workspace_bytes, void* stream, const char* who) {
+                  const uint64_t* offset_dev, const uint64_t* row_keys, void* workspace, size_t workspace_bytes,
+                  void* stream, const char* who) {
   NVL_REQUIRE(logits && temperatures && (out || out_packed) && workspace, "%s: null pointer", who);
   NVL_REQUIRE(batch >= 0 && batch <= 65535, "%s: batch=%lld out of range [0, 65535]", who, (long long)batch);
   NVL_REQUIRE(vocab > 0 && col_offset >= 0 && col_offset + vocab < (1ll << 31) - 8, "%s: bad vocab=%lld (+%lld)", who,
@@ -170,7 +178,7 @@ int sample_common(const void* logits, int64_t logits_row_stride, const float* te
   int* ws_idx = (int*)(ws_val + (size_t)batch * kSplits);
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(sample_partial_kernel, dim3(kSplits, (unsigned)batch), dim3(256), 0, s, (const bf16_t*)logits,
-                     logits_row_stride, temperatures, vocab, col_offset, seed, offset, offset_dev, ws_val, ws_idx);
+                     logits_row_stride, temperatures, vocab, col_offset, seed, offset, offset_dev, row_keys, ws_val, ws_idx);
   hipLaunchKernelGGL(sample_merge_kernel, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, s, ws_val, ws_idx, 1,
                      (int64_t)0, kSplits, out, out_packed, batch);
   return nvl_check_launch(who);
@@ -179,18 +187,19 @@ int sample_common(const void* logits, int64_t logits_row_stride, const float* te
 
 extern "C" int nvl_sample(const void* logits, int64_t logits_row_stride, const float* temperatures, int64_t* out,
                           int64_t batch, int64_t vocab, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                          void* workspace, size_t workspace_bytes, void* stream) {
+                          const uint64_t* row_keys, void* workspace, size_t workspace_bytes, void* stream) {
   return sample_common(logits, logits_row_stride, temperatures, out, nullptr, batch, vocab, 0, seed, offset,
-                       offset_dev, workspace, workspace_bytes, stream, "nvl_sample");
+                       offset_dev, row_keys, workspace, workspace_bytes, stream, "nvl_sample");
 }
 
 extern "C" int nvl_sample_shard(const void* logits, int64_t logits_row_stride, const float* temperatures,
                                 void* best_packed, int64_t batch, int64_t vocab_local, int64_t col_offset,
-                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev, void* workspace,
-                                size_t workspace_bytes, void* stream) {
+                                uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                const uint64_t* row_keys, void* workspace, size_t workspace_bytes, void* stream) {
   NVL_REQUIRE(((uintptr_t)best_packed) % 8 == 0, "nvl_sample_shard: best_packed must be 8-byte aligned");
   return sample_common(logits, logits_row_stride, temperatures, nullptr, (uint32_t*)best_packed, batch, vocab_local,
-                       col_offset, seed, offset, offset_dev, workspace, workspace_bytes, stream, "nvl_sample_shard");
+                       col_offset, seed, offset, offset_dev, row_keys, workspace, workspace_bytes, stream,
+                       "nvl_sample_shard");
 }
 
 extern "C" int nvl_sample_merge(const void* best_packed, int parts, int64_t part_stride_bytes, int64_t* out,

@@ -58,6 +58,7 @@ class LLMEngine:
         # serial loop for A/B measurements
         self._lookahead = os.environ.get("NVL_LOOKAHEAD", "1") != "0"
         self._unfilled = None              # sequences of an in-flight lookahead step whose token values are pending
+        self._requests = 0                 # ordinal of the next request (the sampler's per-sequence key)
         self._exited = False
         atexit.register(self.exit)
 
@@ -95,8 +96,14 @@ class LLMEngine:
             f"max_model_len ({self.config.max_model_len})")
         return prompt
 
+    def _new_sequence(self, prompt: list[int], sampling_params: SamplingParams) -> Sequence:
+        seq = Sequence(prompt, sampling_params)
+        seq.rng_key = self._requests
+        self._requests += 1
+        return seq
+
     def add_request(self, prompt: str | list[int], sampling_params: SamplingParams):
-        self.scheduler.add(Sequence(self._checked_prompt(prompt, sampling_params), sampling_params))
+        self.scheduler.add(self._new_sequence(self._checked_prompt(prompt, sampling_params), sampling_params))
 
     def step(self):
         seqs, is_prefill = self.scheduler.schedule()
@@ -125,12 +132,10 @@ class LLMEngine:
         step N+2 run while the GPU works. The GPU queue never drains between decode steps. With `ignore_eos` the
         scheduler and block manager go through exactly the serial loop's operations; a sequence that samples EOS
         is discovered one step late and finished retroactively (sched.Scheduler.fill_tokens): its own outputs are the
-        serial loop's, only its last step's row was computed for nothing. At T = 0 (and with `ignore_eos` at any
-        temperature) every sequence's outputs are the serial loop's. At T > 0 WITHOUT `ignore_eos` they are not
-        stream-identical: the sampler's counter-based draw is keyed by (step, batch row), the retroactively finished
-        sequence still occupies a row of step N+1, so the sequences behind it in that batch draw other random
-        numbers than in the serial loop (same distribution, different stream; NVL_LOOKAHEAD=0 gives the serial
-        stream). Finished sequences of a lookahead step
+        serial loop's, only its last step's row was computed for nothing. That holds at any temperature: the
+        sampler's counter-based draw is keyed by (seed, request ordinal, token position) — `Sequence.rng_key`, staged
+        per row as `rkey` — not by (step, batch row), so the row a retroactively finished sequence still occupies in
+        step N+1 does not shift anybody else's random numbers (tests/test_engine_host.py, tests/test_e2e_gpu.py). Finished sequences of a lookahead step
         are reported by the next call.
         `pending`: None, or (seqs, is_prefill, staged) scheduled by the previous call.
         Returns (finished outputs, num_tokens, pending for the next call)."""
@@ -185,7 +190,7 @@ class LLMEngine:
         # validate EVERY request before enqueueing ANY: a refused request must not leave its predecessors queued
         checked = [self._checked_prompt(prompt, sp) for prompt, sp in zip(prompts, sampling_params)]
         for prompt, sp in zip(checked, sampling_params):
-            self.scheduler.add(Sequence(prompt, sp))
+            self.scheduler.add(self._new_sequence(prompt, sp))
         done: dict[int, list[int]] = {}
         prefill_tps = decode_tps = 0.0
         pending = None                      # batch already scheduled (and maybe staged) by the lookahead

@@ -371,7 +371,7 @@ class ModelRunner:
         self.max_blocks = -(-cfg.max_model_len // self.block_size)
         mb, w = self.max_bs, self.max_blocks
         self.dstage = _Stage([
-            ("ids", np.int64, (mb,)), ("pos", np.int64, (mb,)), ("rng", np.uint64, (2,)),
+            ("ids", np.int64, (mb,)), ("pos", np.int64, (mb,)), ("rng", np.uint64, (2,)), ("rkey", np.int64, (mb,)),
             ("slots", np.int32, (mb,)), ("ctx", np.int32, (mb,)), ("temps", np.float32, (mb,)),
             ("src", np.int32, (mb,)), ("bt", np.int32, (mb, w)),
         ], self.device, host_copies=2)
@@ -386,7 +386,7 @@ class ModelRunner:
         nt = cfg.max_num_batched_tokens
         ns = min(cfg.max_num_seqs, nt)
         self.pstage = _Stage([
-            ("ids", np.int64, (nt,)), ("pos", np.int64, (nt,)), ("rng", np.uint64, (2,)),
+            ("ids", np.int64, (nt,)), ("pos", np.int64, (nt,)), ("rng", np.uint64, (2,)), ("rkey", np.int64, (ns,)),
             ("slots", np.int32, (nt,)), ("cu_q", np.int32, (ns + 1,)), ("cu_k", np.int32, (ns + 1,)),
             ("temps", np.float32, (ns,)), ("bt", np.int32, (ns, w)),
         ], self.device)
@@ -492,6 +492,7 @@ class ModelRunner:
             else:                                              # warm-up: no cache, nothing to store
                 have_slots = False
             st["temps"][i] = seq.temperature
+            st["rkey"][i] = seq.rng_key | (end << 32)          # the draw of the token that will sit at position `end`
             n += lq
         ns = len(seqs)
         paged = int(cu_k[ns]) > int(cu_q[ns])                  # some K/V must come from the cache
@@ -523,6 +524,8 @@ class ModelRunner:
                 st["ids"][i] = seqs[i].last_token
         st["pos"][:n] = lens - 1
         st["ctx"][:n] = lens
+        # sampler key per row: (request ordinal, position of the token being drawn) — independent of the batch row
+        st["rkey"][:n] = np.fromiter((s.rng_key for s in seqs), dtype=np.int64, count=n) | (lens << 32)
         last_blk = np.fromiter((s.block_table[-1] for s in seqs), dtype=np.int64, count=n)
         st["slots"][:n] = last_blk * bs + (lens - 1) % bs
         st["temps"][:n] = [s.temperature for s in seqs]
@@ -551,10 +554,13 @@ class ModelRunner:
 
     # ------------------------------------------------------------------ forward
     def _next_rng(self, st: _Stage) -> None:
+        """`rng[0]` is the stream offset added to every row's draw: constant 0 — the per-row keys (`rkey`: request
+        ordinal | position << 32) already make every (sequence, position) draw unique, and a step counter here would
+        tie a request's tokens to how many steps other requests took before it."""
         self.step_count += 1
-        st.np["rng"][0] = self.step_count
+        st.np["rng"][0] = 0
 
-    def _sample(self, hidden, temps, out, rng, sampler):
+    def _sample(self, hidden, temps, out, rng, sampler, rkey=None):
         """lm_head + sampler on the current stream; TP > 1: every rank samples its vocabulary shard and the
         per-row winners are merged on every rank (no [B, V] gather, embed_head.py:62-65)."""
         col0 = self.rank * self.geo["vocab_per_rank"]
@@ -563,13 +569,14 @@ class ModelRunner:
         if ctx.is_prefill:                                   # only each sequence's last token is sampled
             rows = hidden[(ctx.cu_seqlens_q[1:] - 1).long()].contiguous()
         # one pass over the vocabulary matrix, logits never in HBM (nvl_lmhead_sample); None = shape not covered
-        if sampler.forward_lm_head(rows, self.model.lm_head.weight, temps, out, col0, offset_dev=rng) is not None:
+        if sampler.forward_lm_head(rows, self.model.lm_head.weight, temps, out, col0, offset_dev=rng,
+                                   row_keys=rkey) is not None:
             return
         if self.world_size == 1:
-            sampler(self.model.compute_logits(hidden), temps, out=out, offset_dev=rng)
+            sampler(self.model.compute_logits(hidden), temps, out=out, offset_dev=rng, row_keys=rkey)
         else:
             logits = self.model.compute_logits_shard(hidden)
-            sampler.forward_shard(logits, temps, col0, out, offset_dev=rng)
+            sampler.forward_shard(logits, temps, col0, out, offset_dev=rng, row_keys=rkey)
 
     def _decode_rows(self, r0: int, r1: int, ws, sampler, plan=None):
         """Decode forward for rows [r0, r1) of the static device buffers, on the current stream."""
@@ -580,7 +587,7 @@ class ModelRunner:
                     block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len,
                     decode_plan=plan)
         hidden = self.model(t["ids"][r0:r1], t["pos"][r0:r1])
-        self._sample(hidden, t["temps"][r0:r1], self.tokens_dev[r0:r1], t["rng"][:1], sampler)
+        self._sample(hidden, t["temps"][r0:r1], self.tokens_dev[r0:r1], t["rng"][:1], sampler, t["rkey"][r0:r1])
         reset_context()
 
     @torch.inference_mode()
@@ -670,7 +677,7 @@ class ModelRunner:
         set_context(True, t["cu_q"][:ns + 1], t["cu_k"][:ns + 1], info["max_q"], info["max_k"],
                     t["slots"][:n] if info["have_slots"] else None, None, t["bt"][:ns] if info["paged"] else None)
         hidden = self.model(t["ids"][:n], t["pos"][:n])
-        self._sample(hidden, t["temps"][:ns], self.tokens_dev[:ns], t["rng"][:1], self.sampler)
+        self._sample(hidden, t["temps"][:ns], self.tokens_dev[:ns], t["rng"][:1], self.sampler, t["rkey"][:ns])
         reset_context()
 
     def _run_prefill(self, seqs: list[Sequence]) -> list[int] | None:

@@ -24,7 +24,7 @@ class SequenceStatus(Enum):
 class Sequence:
     __slots__ = ("seq_id", "status", "token_ids", "last_token", "num_tokens", "num_prompt_tokens",
                  "num_cached_tokens", "num_scheduled_tokens", "is_prefill", "block_table", "table_gen",
-                 "temperature", "max_tokens", "ignore_eos")
+                 "temperature", "max_tokens", "ignore_eos", "rng_key")
 
     block_size = 256          # set by the engine from Config.kvcache_block_size
     counter = count()
@@ -32,6 +32,9 @@ class Sequence:
     def __init__(self, token_ids: list[int], sampling_params: SamplingParams | None = None):
         sp = sampling_params if sampling_params is not None else SamplingParams()
         self.seq_id = next(Sequence.counter)
+        # identity of this request in the sampler's counter-based draw (with the token position): the engine sets
+        # it to the request's ordinal within THAT engine, so a fresh engine with the same seed reproduces a run
+        self.rng_key = self.seq_id
         self.status = SequenceStatus.WAITING
         self.token_ids = list(token_ids)
         self.last_token = token_ids[-1]

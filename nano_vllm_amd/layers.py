@@ -183,7 +183,10 @@ class Sampler(nn.Module):
         self.capture: list | None = None        # tests: every step's logits (fp32, host) are appended here
 
     def forward(self, logits: torch.Tensor, temperatures: torch.Tensor, out: torch.Tensor | None = None,
-                offset_dev: torch.Tensor | None = None) -> torch.Tensor:
+                offset_dev: torch.Tensor | None = None, row_keys: torch.Tensor | None = None) -> torch.Tensor:
+        """`row_keys` (int64 [B]: request ordinal | position << 32, extension): each row's draw is keyed by its
+        sequence and position instead of by its row in this batch (the reference's generator is consumed in batch
+        order, sampler.py:11)."""
         b = logits.shape[0]
         need = ops.sample_workspace_bytes(max(b, 512))
         if self._ws is None or self._ws.numel() < need or self._ws.device != logits.device:
@@ -194,10 +197,12 @@ class Sampler(nn.Module):
         self.calls += 1
         if self.capture is not None:
             self.capture.append(logits.float().cpu())
-        return ops.sample(logits, temperatures, self.seed, offset, self._ws, out=out, offset_dev=offset_dev)
+        return ops.sample(logits, temperatures, self.seed, offset, self._ws, out=out, offset_dev=offset_dev,
+                          row_keys=row_keys)
 
     def forward_lm_head(self, hidden: torch.Tensor, weight: torch.Tensor, temperatures: torch.Tensor, out: torch.Tensor,
-                        col_offset: int = 0, offset_dev: torch.Tensor | None = None) -> torch.Tensor | None:
+                        col_offset: int = 0, offset_dev: torch.Tensor | None = None,
+                        row_keys: torch.Tensor | None = None) -> torch.Tensor | None:
         """lm_head GEMM + sampling in one pass (nvl_lmhead_sample): `hidden` [B, K] are the rows to sample from,
         `weight` this rank's [V/tp, K] lm_head shard. Returns None when the shape is not covered (B > 192): the
         caller then runs the GEMM and `forward` / `forward_shard`. TP > 1: the shard winners are exchanged and
@@ -221,11 +226,11 @@ class Sampler(nn.Module):
         _, size = tp.world()
         if size == 1:
             ops.lmhead_sample(hidden, weight, temperatures, self.seed, offset, self._lm_ws, out=out, logits_out=logits,
-                              offset_dev=offset_dev)
+                              offset_dev=offset_dev, row_keys=row_keys)
         else:
             self._pair_buffers(b, size, hidden.device)
             ops.lmhead_sample(hidden, weight, temperatures, self.seed, offset, self._lm_ws, out_packed=self._mine,
-                              logits_out=logits, col_offset=col_offset, offset_dev=offset_dev)
+                              logits_out=logits, col_offset=col_offset, offset_dev=offset_dev, row_keys=row_keys)
             tp.all_gather_small(self._mine, self._pairs)
             ops.sample_merge(self._pairs, size, b, out)
         if logits is not None:
@@ -247,7 +252,7 @@ class Sampler(nn.Module):
         self._mine, self._pairs = self._bufs[rows]
 
     def forward_shard(self, logits: torch.Tensor, temperatures: torch.Tensor, col_offset: int, out: torch.Tensor,
-                      offset_dev: torch.Tensor | None = None) -> torch.Tensor:
+                      offset_dev: torch.Tensor | None = None, row_keys: torch.Tensor | None = None) -> torch.Tensor:
         """Vocab-parallel sampling (TP > 1): `logits` is this rank's [B, V/tp] shard starting at global column
         `col_offset`. Each rank reduces its shard to one {key, index} pair per row, the pairs (8 B per row)
         are all-gathered over xGMI and merged — same draw as `forward` on the gathered logits, on EVERY rank,
@@ -262,7 +267,8 @@ class Sampler(nn.Module):
         self.calls += 1
         if self.capture is not None:
             self.capture.append(logits.float().cpu())
-        ops.sample_shard(logits, temperatures, col_offset, self.seed, offset, self._ws, self._mine, offset_dev=offset_dev)
+        ops.sample_shard(logits, temperatures, col_offset, self.seed, offset, self._ws, self._mine, offset_dev=offset_dev,
+                         row_keys=row_keys)
         tp.all_gather_small(self._mine, self._pairs)
         return ops.sample_merge(self._pairs, size, b, out)
 
@@ -329,11 +335,15 @@ def _decode_sized(x: torch.Tensor) -> bool:
 
 # ---- choice of the decode GEMM ---------------------------------------------------------------------------------
 # K <= 1024 (Qwen3-0.6B): the skinny kernel (nvl_linear_decode), by shape rule. Deep reductions (Qwen3-8B / 32B, full
-# width or per-rank): the wide-tile streaming kernel (nvl_linear_wide) WHERE IT IS FASTER than the library GEMM on this
-# device — decided by timing both once per (rows, n, k, mode) the first time the shape is seen outside a graph capture
-# (the runner's eager warm-up call of every bucket precedes its capture), with the caches flushed before every
-# sample because in the real step every layer's weights come from HBM. NVL_GEMM_WIDE=0 never uses it, =1 always
-# (whenever the plan covers the shape), default "auto".
+# width or per-rank): the wide-tile streaming kernel (nvl_linear_wide) on the module's tile-packed weight copy, by a
+# DETERMINISTIC rule read off the measurements on MI355X (profiles/r03_gemm_wide_packed_vs_rowmajor.json: ours / hipBLASLt
+# at 16 / 64 / 144 / 256 rows for every Qwen3-8B, 32B, 32B/TP4 and 32B/TP8 projection): with one row group (<= 144 rows)
+# it is faster than the library GEMM on all but two of the 48 (shape, rows) pairs (each within 2.4 us); with two row
+# groups (145-256 rows) every workgroup pair streams the same weights twice, which pays only while the matrix is small
+# (<= 90 MB). The same shapes therefore take the same kernel — hence the same bf16 rounding — in every run.
+# NVL_GEMM_WIDE=0 never uses it, =1 always (whenever the plan covers the shape), =tune decides by timing both once per
+# (rows, n, k, mode) the first time the shape is seen outside a graph capture (a new device / shape family).
+_WIDE_TWO_GROUP_MAX_BYTES = 90e6
 _wide_choice: dict[tuple, bool] = {}
 _wide_scratch: dict[tuple, torch.Tensor] = {}
 _flush: dict[int, torch.Tensor] = {}
@@ -393,6 +403,8 @@ def _use_wide(x: torch.Tensor, weight: torch.Tensor, mode: int, packed: torch.Te
         c = False
     elif policy == "1":
         c = True
+    elif policy != "tune":
+        c = m <= 144 or (m <= 288 and n * k * 2 <= _WIDE_TWO_GROUP_MAX_BYTES)
     elif torch.cuda.is_current_stream_capturing():
         return False                                   # an untimed shape inside a capture: library GEMM, not cached
     else:

@@ -55,13 +55,13 @@ SIGNATURES = {
                                         c_int, c_void_p, c_void_p]),
     "nvl_sample_workspace_bytes": (c_size_t, [c_int64]),
     "nvl_sample": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_uint64, c_uint64, c_void_p,
-                           c_void_p, c_size_t, c_void_p]),
+                           c_void_p, c_void_p, c_size_t, c_void_p]),
     "nvl_sample_shard": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64,
-                                 c_void_p, c_void_p, c_size_t, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nvl_sample_merge": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "nvl_lmhead_sample_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "nvl_lmhead_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
-                                  c_int64, c_uint64, c_uint64, c_void_p, c_void_p, c_size_t, c_void_p]),
+                                  c_int64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nvl_feed_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "nvl_allreduce_create": (c_int, [c_int, c_int, c_int64, ctypes.POINTER(c_void_p)]),
     "nvl_allreduce_uid": (c_int, [c_void_p, c_void_p]),
@@ -437,9 +437,18 @@ def sample_workspace_bytes(max_batch: int) -> int:
     return lib().nvl_sample_workspace_bytes(max_batch)
 
 
+def _keys_ptr(row_keys: torch.Tensor | None, b: int) -> int | None:
+    if row_keys is None:
+        return None
+    assert row_keys.dtype == torch.int64 and row_keys.is_contiguous() and row_keys.numel() >= b and row_keys.is_cuda
+    return row_keys.data_ptr()
+
+
 def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: int, workspace: torch.Tensor,
-           out: torch.Tensor | None = None, offset_dev: torch.Tensor | None = None) -> torch.Tensor:
-    """logits bf16 [B, V]; temperatures fp32 [B] (0 => argmax); returns int64 [B]."""
+           out: torch.Tensor | None = None, offset_dev: torch.Tensor | None = None,
+           row_keys: torch.Tensor | None = None) -> torch.Tensor:
+    """logits bf16 [B, V]; temperatures fp32 [B] (0 => argmax); returns int64 [B]. `row_keys` (int64 [B] holding
+    sequence_id | position << 32): draws keyed by (sequence, position) instead of by batch row."""
     _dev(logits, "logits")
     assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype == torch.bfloat16
     assert temperatures.dtype == torch.float32
@@ -448,13 +457,14 @@ def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: 
         out = torch.empty(b, dtype=torch.int64, device=logits.device)
     _check(lib().nvl_sample(logits.data_ptr(), logits.stride(0), temperatures.data_ptr(), out.data_ptr(), b, vocab,
                             seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF,
-                            offset_dev.data_ptr() if offset_dev is not None else None, workspace.data_ptr(),
-                            workspace.numel() * workspace.element_size(), _stream()))
+                            offset_dev.data_ptr() if offset_dev is not None else None, _keys_ptr(row_keys, b),
+                            workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
     return out
 
 
 def sample_shard(logits: torch.Tensor, temperatures: torch.Tensor, col_offset: int, seed: int, offset: int,
-                 workspace: torch.Tensor, out_packed: torch.Tensor, offset_dev: torch.Tensor | None = None) -> torch.Tensor:
+                 workspace: torch.Tensor, out_packed: torch.Tensor, offset_dev: torch.Tensor | None = None,
+                 row_keys: torch.Tensor | None = None) -> torch.Tensor:
     """This rank's vocabulary shard -> one {key bits, global index} pair per row (int32 [B, 2])."""
     _dev(logits, "logits")
     assert logits.dim() == 2 and logits.stride(1) == 1 and logits.dtype == torch.bfloat16
@@ -463,8 +473,8 @@ def sample_shard(logits: torch.Tensor, temperatures: torch.Tensor, col_offset: i
     assert out_packed.numel() >= 2 * b
     _check(lib().nvl_sample_shard(logits.data_ptr(), logits.stride(0), temperatures.data_ptr(), out_packed.data_ptr(), b,
                                   vocab, col_offset, seed & 0xFFFFFFFFFFFFFFFF, offset & 0xFFFFFFFFFFFFFFFF,
-                                  offset_dev.data_ptr() if offset_dev is not None else None, workspace.data_ptr(),
-                                  workspace.numel() * workspace.element_size(), _stream()))
+                                  offset_dev.data_ptr() if offset_dev is not None else None, _keys_ptr(row_keys, b),
+                                  workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
     return out_packed
 
 
@@ -485,7 +495,7 @@ def lmhead_sample_workspace_bytes(batch: int, vocab_local: int, k: int) -> int:
 def lmhead_sample(x: torch.Tensor, weight: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: int,
                   workspace: torch.Tensor, out: torch.Tensor | None = None, out_packed: torch.Tensor | None = None,
                   logits_out: torch.Tensor | None = None, col_offset: int = 0,
-                  offset_dev: torch.Tensor | None = None):
+                  offset_dev: torch.Tensor | None = None, row_keys: torch.Tensor | None = None):
     """Sample from softmax((x @ weight.T) / T) without materialising the logits (x [B, K], weight [V, K] bf16)."""
     _dev(x, "x")
     assert x.dim() == 2 and x.is_contiguous() and weight.is_contiguous()
@@ -498,8 +508,8 @@ def lmhead_sample(x: torch.Tensor, weight: torch.Tensor, temperatures: torch.Ten
         x.data_ptr(), weight.data_ptr(), temperatures.data_ptr(), out.data_ptr() if out is not None else None,
         out_packed.data_ptr() if out_packed is not None else None,
         logits_out.data_ptr() if logits_out is not None else None, b, v, k, col_offset, seed & 0xFFFFFFFFFFFFFFFF,
-        offset & 0xFFFFFFFFFFFFFFFF, offset_dev.data_ptr() if offset_dev is not None else None, workspace.data_ptr(),
-        workspace.numel() * workspace.element_size(), _stream()))
+        offset & 0xFFFFFFFFFFFFFFFF, offset_dev.data_ptr() if offset_dev is not None else None, _keys_ptr(row_keys, b),
+        workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
     return out if out is not None else out_packed
 
 

@@ -147,6 +147,30 @@ def test_sampling_temperature_runs_and_is_seeded(tiny_ckpt):
     assert all(len(t) == 12 for t in res[0])
 
 
+def test_lookahead_equals_serial_when_sampled_eos_ends_sequences(tiny_ckpt, monkeypatch):
+    """T = 0.8 WITHOUT ignore_eos: sequences end on a sampled EOS (discovered one step late by the lookahead, whose
+    retroactively finished sequence still occupies a row of the next step). The sampler keys its draw by (request
+    ordinal, token position), not by (step, batch row), so every request gets the serial loop's tokens."""
+    from nano_vllm_amd import LLM, SamplingParams
+    prompts = _prompts(24, 5, 200, 512, seed=51)
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        llm = LLM(tiny_ckpt, enforce_eager=False, max_model_len=1024, num_kvcache_blocks=64, max_num_seqs=32, seed=11)
+        llm.config.eos = llm.scheduler.eos = 7                       # a token the tiny model samples often enough
+        outs = llm.generate(prompts, SamplingParams(temperature=0.8, max_tokens=48), use_tqdm=False)
+        llm.exit()
+        for k in env:
+            monkeypatch.delenv(k)
+        return [o["token_ids"] for o in outs]
+
+    look, serial = run(), run(NVL_LOOKAHEAD="0")
+    ended = sum(t[-1] == 7 and len(t) < 48 for t in serial)
+    print(f"{ended}/24 sequences ended on a sampled EOS")
+    assert ended >= 3 and look == serial
+
+
 def test_string_prompts_and_eos(tiny_ckpt):
     from nano_vllm_amd import LLM, SamplingParams
     llm = LLM(tiny_ckpt, enforce_eager=True, max_model_len=1024, num_kvcache_blocks=16)

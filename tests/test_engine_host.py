@@ -31,8 +31,13 @@ from nano_vllm_amd.engine.seq import Sequence
 VOCAB = 1000
 
 
-def _next_token(ids, pos):
-    return (np.asarray(ids, dtype=np.int64) * 1103515245 + np.asarray(pos, dtype=np.int64) * 12345 + 1) % VOCAB
+def _next_token(ids, pos, rkey=None):
+    """The stand-in model + sampler: a function of (input id, position) and — like the real sampler's counter-based
+    draw — of the row's staged key (request ordinal | position << 32), never of the batch row or the step number."""
+    t = np.asarray(ids, dtype=np.int64) * 1103515245 + np.asarray(pos, dtype=np.int64) * 12345 + 1
+    if rkey is not None:
+        t = t + (np.asarray(rkey, dtype=np.int64) % 1000003) * 7919
+    return t % VOCAB
 
 
 class _HF:
@@ -75,13 +80,14 @@ class FakeRunner(ModelRunner):
             if s.last_token != Scheduler.PLACEHOLDER:
                 assert ids[i] == s.last_token, (i, ids[i], s.last_token)
             assert st["pos"][i] == s.num_tokens - 1 and st["ctx"][i] == s.num_tokens
+            assert st["rkey"][i] == s.rng_key | (s.num_tokens << 32)          # sampler key: (request, position drawn)
             assert st["slots"][i] == s.block_table[-1] * bs + (s.num_tokens - 1) % bs
             row = st["bt"][i]
             assert list(row[:len(s.block_table)]) == s.block_table, (i, s.seq_id, list(row[:8]), s.block_table)
             assert (row[len(s.block_table):] == -1).all()
             self.checked_rows += 1
         assert (st["ctx"][n:self.max_bs] == 0).all() and (st["slots"][n:self.max_bs] == -1).all()
-        toks = _next_token(ids, st["pos"][:n])
+        toks = _next_token(ids, st["pos"][:n], st["rkey"][:n])
         self.tokens[:n] = toks
         self._inflight.append((n, toks.copy()))
 
@@ -94,7 +100,7 @@ class FakeRunner(ModelRunner):
         st = self.pstage.np
         cu = st["cu_q"][:info["ns"] + 1]
         last = cu[1:] - 1
-        toks = _next_token(st["ids"][last], st["pos"][last])
+        toks = _next_token(st["ids"][last], st["pos"][last], st["rkey"][:info["ns"]])
         n = 0
         for i, s in enumerate(seqs):                        # staged chunk == the sequence's scheduled tokens
             lq = s.num_scheduled_tokens
@@ -119,6 +125,7 @@ def _engine(lookahead: bool, **cfg_kw):
     eng.scheduler = Scheduler(cfg)
     eng._lookahead = lookahead
     eng._unfilled = None
+    eng._requests = 0
     eng._exited = True
     return eng
 
@@ -311,9 +318,17 @@ def test_decode_gemm_chooser_policies(monkeypatch):
     assert layers.decode_linear(xd, deep, ops.LINEAR_SILU) == "wide" and calls == ["plan", "wide"]   # decision cached
     calls.clear()                 # a module with a tile-packed copy streams THAT (its own cached decision)
     assert layers.decode_linear(xd, deep, ops.LINEAR_SILU, packed=deep.clone()) == "wide" and calls[-1] == "wide-packed"
-    # auto: timed outside a capture, deferred (not cached) inside one
+    # auto: a deterministic rule (rows / matrix size), the same in every run
     layers._wide_choice.clear()
     monkeypatch.setenv("NVL_GEMM_WIDE", "auto")
+    assert layers.decode_linear(xd, deep, ops.LINEAR_BF16) == "wide"                        # 16 rows: one row group
+    x200 = torch.zeros(200, 4096)
+    assert layers.decode_linear(x200, deep, ops.LINEAR_BF16) == "wide"                      # two row groups, small matrix
+    huge = torch.zeros(16384, 4096)                                                         # 134 MB: library GEMM
+    assert layers.decode_linear(x200, huge, ops.LINEAR_BF16) is None
+    # tune: timed outside a capture, deferred (not cached) inside one
+    layers._wide_choice.clear()
+    monkeypatch.setenv("NVL_GEMM_WIDE", "tune")
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: True)
     assert layers.decode_linear(xd, deep, ops.LINEAR_PARTIAL) is None and layers.wide_choices() == {}
     monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)

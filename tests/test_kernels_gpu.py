@@ -841,6 +841,35 @@ def test_sampler_distribution(ops):
     assert chi2 < dof + 5 * math.sqrt(2 * dof), (chi2, dof)
 
 
+def test_sampler_row_keys_make_the_draw_independent_of_the_batch_row(ops):
+    """row_keys = sequence | position << 32: a sequence draws the same token wherever it sits in the batch and
+    whatever else is in the batch; without keys the draw follows the batch row."""
+    b, v = 12, 4096
+    logits = (torch.randn(b, v, generator=g(91)) * 2).to(BF16)
+    temps = torch.full((b,), 0.9)
+    keys = torch.arange(b, dtype=torch.int64) * 7 + 3 + (torch.arange(b, dtype=torch.int64) + 100 << 32)
+    ws = torch.empty(ops.sample_workspace_bytes(512), dtype=torch.uint8, device="cuda")
+    base = ops.sample(dev(logits), dev(temps), 5, 0, ws, row_keys=dev(keys)).cpu()
+    perm = torch.randperm(b, generator=g(92))
+    shuffled = ops.sample(dev(logits[perm]), dev(temps), 5, 0, ws, row_keys=dev(keys[perm])).cpu()
+    assert torch.equal(shuffled, base[perm])
+    sub = perm[:5]                                             # a smaller batch holding some of the same sequences
+    assert torch.equal(ops.sample(dev(logits[sub]), dev(temps[:5]), 5, 0, ws, row_keys=dev(keys[sub])).cpu(), base[sub])
+    # the key's high word is an offset: (row 3, position p) without keys == key (3 | p << 32) at offset 0
+    unkeyed = ops.sample(dev(logits), dev(temps), 5, 100 + 3, ws).cpu()
+    k3 = torch.tensor([3 + ((100 + 3) << 32)], dtype=torch.int64)
+    assert int(ops.sample(dev(logits[3:4]), dev(temps[:1]), 5, 0, ws, row_keys=dev(k3)).cpu()) == int(unkeyed[3])
+    assert not torch.equal(ops.sample(dev(logits[perm]), dev(temps), 5, 0, ws).cpu(), base[perm]) or b < 3
+    # vocab-parallel shards with keys merge to the keyed full-row draw
+    half = v // 2
+    packed = torch.zeros(2, 512, 2, dtype=torch.int32, device="cuda")
+    for r in range(2):
+        ops.sample_shard(dev(logits[:, r * half:(r + 1) * half].contiguous()), dev(temps), r * half, 5, 0, ws, packed[r],
+                         row_keys=dev(keys))
+    out = torch.empty(b, dtype=torch.int64, device="cuda")
+    assert torch.equal(ops.sample_merge(packed, 2, b, out).cpu(), base)
+
+
 def test_sampler_shards_merge_to_the_full_row_draw(ops):
     """Vocab-parallel sampling (nvl_sample_shard + nvl_sample_merge) == nvl_sample on the concatenated row, for
     T > 0 (same Philox stream: keyed by the GLOBAL column) and T = 0 (lowest index on ties across shards)."""
