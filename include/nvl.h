@@ -107,7 +107,9 @@ int nvl_silu_mul(const void* x, int64_t x_row_stride, void* y,
  * caller then keeps the library GEMM. */
 int nvl_linear_decode_splits(int64_t m, int n, int k, int mode);
 int nvl_linear_decode(const void* x, const void* weight, void* out,
-                      int64_t m, int n, int k, int mode, void* stream);
+                      int64_t m, int n, int k, int mode, int weight_layout, void* stream);
+/* weight_layout (nvl_linear_decode, nvl_linear_wide): 0 = `weight` is the reference's row-major
+ * [n, k] parameter; 1 = the tile-packed copy made by nvl_pack_weight_tiles (below). */
 
 /* Decode-time linear layers on DEEP reductions (Qwen3-8B / 32B projections, full width and
  * per-rank TP shapes): the same contract as nvl_linear_decode (modes 0 / 1 / 2, reference

@@ -52,7 +52,7 @@ template <int MT, int KB, int NT, int EPI>
 __global__ __launch_bounds__(kNW * 64) void linear_decode_kernel(const bf16_t* __restrict__ x,
                                                                   const bf16_t* __restrict__ w,
                                                                   void* __restrict__ out, int M, int N, int K,
-                                                                  int ko_iters) {
+                                                                  int ko_iters, int packed) {
   static_assert(EPI != EPI_SILU || NT == 2, "SILU pairs a gate tile with an up tile");
   constexpr int T = MT * NT;
   // NT == 1: two accumulation chains per tile (even / odd k blocks) hide the MFMA dependency latency;
@@ -70,12 +70,18 @@ __global__ __launch_bounds__(kNW * 64) void linear_decode_kernel(const bf16_t* _
   const int out_cols = EPI == EPI_SILU ? N / 2 : N;
   unsigned char* xlds = smem_raw + wave * (2 * XT::kBytes);   // this wave's private 2-slot tile ring
 
+  // Weight fragments. Row-major W: lane (l15, lq) reads 16 B of row l15 — every 16-lane group of the wave touches 16
+  // different 128-byte lines, which the CU's address path retires at ~15 B/clk. `packed` (nvl_pack_weight_tiles: the
+  // 16 x 32 sub-matrix of a (tile, k-block) stored as ONE contiguous KiB in lane order): the same fragment is a
+  // contiguous wave load, a quarter of the address-path time. Both are affine in the k block: base + kw * kws + kb * kbs.
+  const int kbs = packed ? 512 : 32;               // elements between consecutive 32-wide k blocks
+  const int kws = packed ? 16 : 1;                 // elements per unit of k
   const bf16_t* wrow[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     // SILU: tile 0 = gate columns, tile 1 = the matching up columns; otherwise NT adjacent tiles
-    const int row = EPI == EPI_SILU ? nt * out_cols + n_tile * 16 + l15 : (n_tile * NT + nt) * 16 + l15;
-    wrow[nt] = w + (int64_t)row * K;
+    const int tile = EPI == EPI_SILU ? nt * (out_cols >> 4) + n_tile : n_tile * NT + nt;
+    wrow[nt] = packed ? w + (int64_t)tile * 16 * K + lane * 8 : w + (int64_t)(tile * 16 + l15) * K + lq * 8;
   }
 
   // x staging geometry: a tile is 64*KB 16-byte chunks; load instruction i moves chunks i*64 + lane, i.e.
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(kNW * 64) void linear_decode_kernel(const bf16_t* _
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb)
-        wf[nt][kb] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[nt] + kw + lq * 8 + kb * 32));
+        wf[nt][kb] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wrow[nt] + kw * kws + kb * kbs));
 
     auto mfma_tile = [&](int mt, const u32x4_t* f) {
 #pragma unroll
@@ -235,6 +241,7 @@ __global__ __launch_bounds__(kNW * 64) void linear_decode_kernel(const bf16_t* _
 struct Plan {
   int kb, ko, split, nt, mt, mgroups;
 };
+thread_local int g_packed = 0;       // weight layout of the call being dispatched (set by nvl_linear_decode)
 
 // Deep-K shapes (several passes of the per-wave K range: Qwen3-8B / 32B projections) are reported as NOT covered: with
 // 16-32 output columns per workgroup every workgroup re-reads all of x (768 workgroups x 144 x 4096 x 2 B = 906 MB of
@@ -297,7 +304,7 @@ int launch(const void* x, const void* w, void* out, int64_t m, int n, int k, con
   const int out_cols = EPI == EPI_SILU ? n / 2 : n;
   const int col_wgs = EPI == EPI_SILU ? out_cols / 16 : out_cols / 16 / NT;
   hipLaunchKernelGGL((linear_decode_kernel<MT, KB, NT, EPI>), dim3(col_wgs, p.split, p.mgroups), dim3(kNW * 64), lds,
-                     s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.ko);
+                     s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.ko, g_packed);
   return nvl_check_launch("nvl_linear_decode");
 }
 
@@ -442,9 +449,11 @@ extern "C" int nvl_linear_decode_splits(int64_t m, int n, int k, int mode) {
 }
 
 extern "C" int nvl_linear_decode(const void* x, const void* weight, void* out, int64_t m, int n, int k, int mode,
-                                 void* stream) {
+                                 int weight_layout, void* stream) {
   NVL_REQUIRE(x && weight && out, "nvl_linear_decode: null pointer");
   NVL_REQUIRE(mode >= 0 && mode <= 2, "nvl_linear_decode: mode=%d (0 bf16, 1 silu*mul, 2 split-K fp32 partials)", mode);
+  NVL_REQUIRE(weight_layout == 0 || weight_layout == 1, "nvl_linear_decode: weight_layout=%d (0 row-major [N, K], 1 tile-packed)", weight_layout);
+  g_packed = weight_layout;
   NVL_REQUIRE(((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out) % 16 == 0,
               "nvl_linear_decode: pointers must be 16-byte aligned");
   Plan p;

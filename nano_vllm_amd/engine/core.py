@@ -132,10 +132,12 @@ class LLMEngine:
         step N+2 run while the GPU works. The GPU queue never drains between decode steps. With `ignore_eos` the
         scheduler and block manager go through exactly the serial loop's operations; a sequence that samples EOS
         is discovered one step late and finished retroactively (sched.Scheduler.fill_tokens): its own outputs are the
-        serial loop's, only its last step's row was computed for nothing. That holds at any temperature: the
-        sampler's counter-based draw is keyed by (seed, request ordinal, token position) — `Sequence.rng_key`, staged
-        per row as `rkey` — not by (step, batch row), so the row a retroactively finished sequence still occupies in
-        step N+1 does not shift anybody else's random numbers (tests/test_engine_host.py, tests/test_e2e_gpu.py). Finished sequences of a lookahead step
+        serial loop's, only its last step's row was computed for nothing. At any temperature every request sees the
+        serial loop's random numbers: the sampler's counter-based draw is keyed by (seed, request ordinal, token
+        position) — `Sequence.rng_key`, staged per row as `rkey` — not by (step, batch row), so the row a
+        retroactively finished sequence still occupies in step N+1 does not shift anybody else's draws
+        (tests/test_engine_host.py proves the equality on a stand-in device; on the GPU the logits of the other rows
+        can still differ in their last bf16 bit, as between any two batch compositions — tests/test_e2e_gpu.py). Finished sequences of a lookahead step
         are reported by the next call.
         `pending`: None, or (seqs, is_prefill, staged) scheduled by the previous call.
         Returns (finished outputs, num_tokens, pending for the next call)."""

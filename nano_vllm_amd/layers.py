@@ -297,13 +297,17 @@ class LinearBase(nn.Module):
 
     def pack_for_decode(self) -> int:
         """After the weights are loaded: keep a tile-packed copy (ops.pack_weight_tiles) of a projection whose decode
-        GEMM is nvl_linear_wide's — deep reductions the skinny kernel does not cover (Qwen3-8B / 32B shapes). The
-        row-major parameter stays: prefill-sized GEMMs run on hipBLASLt from it. Returns the extra bytes.
-        NVL_WIDE_PACKED=0 keeps the row-major weight stream (A/B measurements)."""
+        GEMM is one of the hand-written kernels — the skinny kernel (K <= 1024-3072: Qwen3-0.6B) or the wide-tile one
+        (deep reductions: Qwen3-8B / 32B shapes). The row-major parameter stays: prefill-sized GEMMs run on hipBLASLt
+        from it. Returns the extra bytes. NVL_PACKED_WEIGHTS=0 keeps the row-major weight stream (A/B measurements)."""
         n, k = self.weight.shape
-        if (self.bias is not None or not self.weight.is_cuda or n % 16 or k % 128
-                or os.environ.get("NVL_WIDE_PACKED", "1") == "0" or os.environ.get("NVL_GEMM_WIDE", "auto") == "0"
-                or ops.linear_decode_splits(144, n, k, ops.LINEAR_BF16) or ops.linear_wide_plan(144, n, k, ops.LINEAR_BF16) is None):
+        if (self.bias is not None or not self.weight.is_cuda or n % 16 or k % 32
+                or os.environ.get("NVL_PACKED_WEIGHTS", "1") == "0"):
+            return 0
+        skinny = any(ops.linear_decode_splits(144, n, k, mode) for mode in (ops.LINEAR_BF16, ops.LINEAR_PARTIAL))
+        wide = (k % 128 == 0 and os.environ.get("NVL_GEMM_WIDE", "auto") != "0"
+                and ops.linear_wide_plan(144, n, k, ops.LINEAR_BF16) is not None)
+        if not (skinny or wide):
             return 0
         self.weight_packed = ops.pack_weight_tiles(self.weight.data)
         return self.weight_packed.numel() * 2
@@ -432,6 +436,8 @@ def decode_linear(x: torch.Tensor, weight: torch.Tensor, mode: int, out: torch.T
     m, k = x.shape
     n = weight.shape[0]
     if ops.linear_decode_splits(m, n, k, mode):
+        if packed is not None:
+            return ops.linear_decode(x, packed, mode, out=out, packed=True)
         return ops.linear_decode(x, weight, mode, out=out)
     if _use_wide(x, weight, mode, packed):
         plan = ops.linear_wide_plan(m, n, k, mode)

@@ -27,7 +27,7 @@ SIGNATURES = {
     "nvl_rmsnorm": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_void_p]),
     "nvl_add_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "nvl_linear_decode_splits": (c_int, [c_int64, c_int, c_int, c_int]),
-    "nvl_linear_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "nvl_linear_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "nvl_linear_wide_plan": (c_int, [c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     "nvl_linear_wide": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
                                 c_void_p]),
@@ -197,9 +197,9 @@ def linear_decode_splits(m: int, n: int, k: int, mode: int) -> int:
 
 
 def linear_decode(x: torch.Tensor, weight: torch.Tensor, mode: int = LINEAR_BF16,
-                  out: torch.Tensor | None = None) -> torch.Tensor:
-    """x [M, K] bf16, weight [N, K] bf16 (torch Linear layout). mode 0: bf16 [M, N];
-    mode 1: bf16 [M, N/2] = silu(x.Wgate) * (x.Wup); mode 2: fp32 split-K partials [S, M, N]."""
+                  out: torch.Tensor | None = None, packed: bool = False) -> torch.Tensor:
+    """x [M, K] bf16, weight [N, K] bf16 (torch Linear layout; `packed`: its pack_weight_tiles() copy). mode 0: bf16
+    [M, N]; mode 1: bf16 [M, N/2] = silu(x.Wgate) * (x.Wup); mode 2: fp32 split-K partials [S, M, N]."""
     _dev(x, "x")
     assert x.dim() == 2 and x.is_contiguous() and weight.is_contiguous()
     assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16
@@ -214,7 +214,8 @@ def linear_decode(x: torch.Tensor, weight: torch.Tensor, mode: int = LINEAR_BF16
             out = torch.empty((splits, m, n), dtype=torch.float32, device=x.device)
         else:
             out = torch.empty((m, n // 2 if mode == LINEAR_SILU else n), dtype=torch.bfloat16, device=x.device)
-    _check(lib().nvl_linear_decode(x.data_ptr(), weight.data_ptr(), out.data_ptr(), m, n, k, mode, _stream()))
+    _check(lib().nvl_linear_decode(x.data_ptr(), weight.data_ptr(), out.data_ptr(), m, n, k, mode, 1 if packed else 0,
+                                   _stream()))
     return out
 
 

@@ -69,8 +69,8 @@ def test_host_side_argument_validation_without_gpu():
     assert lib.nvl_allreduce_run(None, 16, 16, 4, 1024, None) == -1
     assert lib.nvl_lmhead_sample_workspace_bytes(131, 151936, 1024) == 594 * 131 * 8
     assert lib.nvl_lmhead_sample_workspace_bytes(300, 151936, 1024) == 0
-    assert lib.nvl_linear_decode(16, 16, 16, 144, 6144, 4096, 0, None) == -3 and b"not covered" in lib.nvl_last_error()
-    assert lib.nvl_linear_decode(None, 16, 16, 144, 4096, 1024, 0, None) == -1
+    assert lib.nvl_linear_decode(16, 16, 16, 144, 6144, 4096, 0, 0, None) == -3 and b"not covered" in lib.nvl_last_error()
+    assert lib.nvl_linear_decode(None, 16, 16, 144, 4096, 1024, 0, 0, None) == -1
     # wide-tile deep-K linear: plan query works without a GPU; uncovered shapes are EUNSUPPORTED, null pointers EINVAL
     import ctypes
     sp, ws = ctypes.c_int(0), ctypes.c_size_t(0)

@@ -296,7 +296,7 @@ def test_decode_gemm_chooser_policies(monkeypatch):
     from nano_vllm_amd import layers, ops
     calls = []
     monkeypatch.setattr(ops, "linear_decode_splits", lambda m, n, k, mode: 1 if k <= 1024 else 0)
-    monkeypatch.setattr(ops, "linear_decode", lambda x, w, mode, out=None: calls.append("skinny") or "skinny")
+    monkeypatch.setattr(ops, "linear_decode", lambda x, w, mode, out=None, packed=False: calls.append("skinny") or "skinny")
     monkeypatch.setattr(ops, "linear_wide_plan", lambda m, n, k, mode: calls.append("plan") or ((2, 64) if n != 48 else None))
     monkeypatch.setattr(ops, "linear_wide", lambda x, w, mode, out=None, workspace=None, packed=False:
                         calls.append("wide-packed" if packed else "wide") or "wide")

@@ -106,6 +106,8 @@ def test_linear_decode_bf16(ops, m, n, k):
     assert ops.linear_decode_splits(m, n, k, ops.LINEAR_BF16) == 1
     y = ops.linear_decode(dev(x), dev(w), ops.LINEAR_BF16)
     assert y.shape == (m, n) and _close_to_rounded(y, acc)
+    # tile-packed weights (what the engine streams): other addresses, the same arithmetic in the same order
+    assert torch.equal(ops.linear_decode(dev(x), ops.pack_weight_tiles(dev(w)), ops.LINEAR_BF16, packed=True), y)
     assert float((ref.bf16_ulp_diff(y.cpu(), acc.to(BF16)) > 0).float().mean()) < 0.01   # order-of-summation flips only
 
 
@@ -115,6 +117,7 @@ def test_linear_decode_silu(ops, m, n, k):
     """gate|up projection with SiluAndMul as the epilogue (models/qwen3.py:90-113, activation.py:8-11)."""
     x, w, acc = _lin_inputs(m, n, k, 22)
     y = ops.linear_decode(dev(x), dev(w), ops.LINEAR_SILU)
+    assert torch.equal(ops.linear_decode(dev(x), ops.pack_weight_tiles(dev(w)), ops.LINEAR_SILU, packed=True), y)
     want = ref.silu_and_mul(acc.to(BF16))
     # the GEMM output may be 1 ulp off before the activation: allow 2 ulp after it, and check closeness
     assert y.shape == (m, n // 2)
@@ -132,6 +135,7 @@ def test_linear_decode_partials_into_add_rmsnorm(ops, m, n, k):
     assert splits >= 1
     parts = ops.linear_decode(dev(x), dev(w), ops.LINEAR_PARTIAL)
     assert parts.shape == (splits, m, n) and parts.dtype == torch.float32
+    assert torch.equal(ops.linear_decode(dev(x), ops.pack_weight_tiles(dev(w)), ops.LINEAR_PARTIAL, packed=True), parts)
     s = parts.sum(0).cpu()
     assert float((s - acc).abs().max()) <= 1e-4 * float(acc.abs().max()) + 1e-5
     r = (torch.randn(m, n, generator=g(26)) * 2).to(BF16)
