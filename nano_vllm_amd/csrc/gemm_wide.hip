@@ -63,7 +63,7 @@ template <int MT, int NT, int NW, int EPI, int RING, bool PACKED>
 __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
                                                                      const bf16_t* __restrict__ w,
                                                                      void* __restrict__ out, int M, int N, int K,
-                                                                     int steps) {
+                                                                     int steps, int paired_tiles) {
   constexpr int kRows = MT * 16;
   constexpr int kStage = kRows * 256;                             // bytes per LDS stage
   static_assert(EPI != EPI_SILU || NT == 2, "SiLU: a wave holds a gate tile and its up tile");
@@ -72,14 +72,25 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
 
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  const int m_base = blockIdx.z * kRows;
+  // Which (column tile, row group)? Plain: (blockIdx.x, blockIdx.z). With TWO row groups (145-288 rows) both groups of
+  // a column tile stream the SAME weights: `paired_tiles` (= the number of column tiles) folds the row group into
+  // blockIdx.x so that the two partners are dispatched back to back ON THE SAME XCD (workgroup id mod 8 picks the XCD;
+  // ids 16 g + c and 16 g + 8 + c are the two row groups of tile 8 g + c): whichever of the two reaches a weight line
+  // first brings it into that XCD's L2 and the other one hits it — the matrix leaves HBM once instead of twice.
+  int tile_x = blockIdx.x, rgroup = blockIdx.z;
+  if (paired_tiles > 0) {
+    tile_x = (int)(blockIdx.x >> 4) * 8 + (int)(blockIdx.x & 7);
+    rgroup = (int)(blockIdx.x >> 3) & 1;
+    if (tile_x >= paired_tiles) return;                           // padding of the grid to a multiple of 16 (whole workgroup)
+  }
+  const int m_base = rgroup * kRows;
   const int out_cols = EPI == EPI_SILU ? N / 2 : N;
   const int64_t k0 = (int64_t)blockIdx.y * steps * kBK;
   const int last = steps - 1;
   // Workgroups walk their K range from different starting steps (wrapping around): rows of W are K * 2 bytes apart, so
   // workgroups marching in lock-step would all touch the same offset inside an 8-16 KiB stride at the same time
   // (the same few HBM channels).
-  const int rot = (int)((blockIdx.x + 3u * blockIdx.y) % (unsigned)steps);
+  const int rot = (int)(((unsigned)tile_x + 3u * blockIdx.y) % (unsigned)steps);
   auto kstep = [&](int s) {                                       // logical step (prefetches past the end clamp) -> k step
     s = (s < last ? s : last) + rot;
     return s >= steps ? s - steps : s;
@@ -141,7 +152,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
 
   // ---- consumer waves ----------------------------------------------------------------------------------------------
   // first output column of this wave's tiles, and the W rows feeding them (SiLU: tile 0 = gate, tile 1 = up)
-  const int n0 = (blockIdx.x * NW + wave) * (GT * 16);
+  const int n0 = (tile_x * NW + wave) * (GT * 16);
   // element strides of this wave's weight pointer per k step / per 32-wide k block: row-major rows advance by k;
   // packed tiles advance by whole KiB blocks (512 elements) of the tile's contiguous run
   constexpr int kWStep = PACKED ? kKB * 512 : kBK;
@@ -449,8 +460,16 @@ int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, in
     }
     attr_set = true;
   }
+  // two row groups: pair them on one XCD (see the kernel); NVL_WIDE_PAIR=0 keeps the plain (tile, split, group) grid
+  static const bool pair_ok = env_int("NVL_WIDE_PAIR", 1) != 0;
+  if (p.mgroups == 2 && pair_ok) {
+    const unsigned gx = (unsigned)((p.tiles + 7) / 8) * 16;
+    hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>), dim3(gx, p.split, 1), dim3((NW + 1) * 64),
+                       lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, p.tiles);
+    return NVL_OK;
+  }
   hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>), dim3(p.tiles, p.split, p.mgroups),
-                     dim3((NW + 1) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps);
+                     dim3((NW + 1) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, 0);
   return NVL_OK;
 }
 

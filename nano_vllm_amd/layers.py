@@ -343,11 +343,13 @@ def _decode_sized(x: torch.Tensor) -> bool:
 # DETERMINISTIC rule read off the measurements on MI355X (profiles/r03_gemm_wide_packed_vs_rowmajor.json: ours / hipBLASLt
 # at 16 / 64 / 144 / 256 rows for every Qwen3-8B, 32B, 32B/TP4 and 32B/TP8 projection): with one row group (<= 144 rows)
 # it is faster than the library GEMM on all but two of the 48 (shape, rows) pairs (each within 2.4 us); with two row
-# groups (145-256 rows) every workgroup pair streams the same weights twice, which pays only while the matrix is small
-# (<= 90 MB). The same shapes therefore take the same kernel — hence the same bf16 rounding — in every run.
+# groups (145-288 rows) the two workgroups of a column tile share its weight stream through one XCD's L2 (paired
+# dispatch, gemm_wide.hip) and win while the matrix is moderate — <= 140 MB for bf16 / SiLU outputs, <= 90 MB for
+# split-K slab outputs (profiles/r03_gemm_wide_m256_paired.json). The same shapes therefore take the same kernel —
+# hence the same bf16 rounding — in every run.
 # NVL_GEMM_WIDE=0 never uses it, =1 always (whenever the plan covers the shape), =tune decides by timing both once per
 # (rows, n, k, mode) the first time the shape is seen outside a graph capture (a new device / shape family).
-_WIDE_TWO_GROUP_MAX_BYTES = 90e6
+_WIDE_TWO_GROUP_MAX_BYTES = {0: 140e6, 1: 140e6, 2: 90e6}      # by ops.LINEAR_* mode
 _wide_choice: dict[tuple, bool] = {}
 _wide_scratch: dict[tuple, torch.Tensor] = {}
 _flush: dict[int, torch.Tensor] = {}
@@ -408,7 +410,7 @@ def _use_wide(x: torch.Tensor, weight: torch.Tensor, mode: int, packed: torch.Te
     elif policy == "1":
         c = True
     elif policy != "tune":
-        c = m <= 144 or (m <= 288 and n * k * 2 <= _WIDE_TWO_GROUP_MAX_BYTES)
+        c = m <= 144 or (m <= 288 and n * k * 2 <= _WIDE_TWO_GROUP_MAX_BYTES[mode])
     elif torch.cuda.is_current_stream_capturing():
         return False                                   # an untimed shape inside a capture: library GEMM, not cached
     else:
