@@ -271,8 +271,9 @@ class ModelRunner:
                 load_model(self.model, config.model)
             # tile-packed copies of the deep-K projections for the decode GEMM (before the KV pool is sized from what
             # is left: a second copy of those weights is the price of a 4x cheaper weight stream per CU)
-            from ..layers import LinearBase
-            self.packed_weight_bytes = sum(m.pack_for_decode() for m in self.model.modules() if isinstance(m, LinearBase))
+            from ..layers import LinearBase, ParallelLMHead
+            self.packed_weight_bytes = sum(m.pack_for_decode() for m in self.model.modules()
+                                           if isinstance(m, (LinearBase, ParallelLMHead)))
             self.sampler = Sampler(seed=config.seed, max_rows=config.max_num_seqs)
             # decode micro-batching (see _forward_decode): second chain's stream, sampler and workspace
             self.microbatches = int(os.environ.get("NVL_MICROBATCHES", "1")) if self.world_size == 1 else 1

@@ -588,12 +588,32 @@ class ParallelLMHead(VocabParallelEmbedding):
     def __init__(self, num_embeddings: int, embedding_dim: int, bias: bool = False):
         assert not bias
         super().__init__(num_embeddings, embedding_dim)
+        self.weight_packed: torch.Tensor | None = None
+
+    def pack_for_decode(self) -> int:
+        """Tile-packed copy of the vocabulary matrix for the decode step's lm_head GEMM on deep hidden sizes
+        (Qwen3-8B / 32B: K >= 2048, where nvl_linear_wide on packed weights beats the library GEMM at <= 144 rows —
+        profiles/r03_gemm_wide_lm_head.json; at K = 1024, Qwen3-0.6B, the library GEMM stays). Returns the extra bytes."""
+        n, k = self.weight.shape
+        if (not self.weight.is_cuda or n % 16 or k % 128 or k < 2048 or os.environ.get("NVL_PACKED_WEIGHTS", "1") == "0"
+                or os.environ.get("NVL_GEMM_WIDE", "auto") == "0" or os.environ.get("NVL_PACKED_LM_HEAD", "1") == "0"
+                or ops.linear_wide_plan(144, n, k, ops.LINEAR_BF16) is None):
+            return 0
+        self.weight_packed = ops.pack_weight_tiles(self.weight.data)
+        return self.weight_packed.numel() * 2
+
+    def _logits(self, x: torch.Tensor) -> torch.Tensor:
+        if self.weight_packed is not None and _decode_sized(x) and x.shape[0] <= 144:
+            y = decode_linear(x, self.weight, ops.LINEAR_BF16, packed=self.weight_packed)
+            if y is not None:
+                return y
+        return F.linear(x, self.weight)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor | None:
         ctx = get_context()
         if ctx.is_prefill:                                   # only each sequence's last token is sampled
             x = x[(ctx.cu_seqlens_q[1:] - 1).long()].contiguous()
-        logits = F.linear(x, self.weight)
+        logits = self._logits(x)
         if self.tp_size == 1:
             return logits
         # reference-shaped result (full logits on rank 0, None elsewhere, embed_head.py:62-65). The engine
@@ -613,4 +633,4 @@ class ParallelLMHead(VocabParallelEmbedding):
         ctx = get_context()
         if ctx.is_prefill:
             x = x[(ctx.cu_seqlens_q[1:] - 1).long()].contiguous()
-        return F.linear(x, self.weight)
+        return self._logits(x)

@@ -16,6 +16,7 @@ MODELS = {
     "32b_tp4": [("qkv", 2560, 5120, 0), ("o", 5120, 2048, 2), ("gate_up", 12800, 5120, 1), ("down", 5120, 6400, 2)],
     "32b_tp8": [("qkv", 1280, 5120, 0), ("o", 5120, 1024, 2), ("gate_up", 6400, 5120, 1), ("down", 5120, 3200, 2)],
     "lm_head": [("lm_head", 151936, 1024, 0)],
+    "lm_head_deep": [("lm_head_8b", 151936, 4096, 0), ("lm_head_32b", 151936, 5120, 0), ("lm_head_32b_tp8", 18992, 5120, 0)],
 }
 
 
@@ -65,7 +66,7 @@ def main():
     for model in models:
         for name, n, k, mode in MODELS[model]:
             for m in (1, 16, 131, 144, 200, 256, 300):
-                if ops.linear_wide_plan(m, n, k, mode) and not (model in ("32b", "lm_head") and m not in (131, 256)):
+                if ops.linear_wide_plan(m, n, k, mode) and not (model in ("32b", "lm_head", "lm_head_deep") and m not in (131, 256)):
                     res["relerr"][f"{model}_{name}_m{m}"] = round(check(m, n, k, mode), 5)
             for m in ms:
                 plan = ops.linear_wide_plan(m, n, k, mode)

@@ -126,6 +126,11 @@ tp3)
 benchfull)
   T0=$(date +%s); timeout 1500 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"; tail -c 400 $OUT/bench_full.err; python -c "
 import json; d=json.load(open('$OUT/bench_full.json')); print(round(d['value']), d['roofline']['frac'], d['roofline']['decode_step']['frac_of_8TBps'], d.get('cpu_baseline')); [print(k, v.get('value'), v.get('error'), v.get('wall_s_incl_engine_start'), (v.get('roofline') or {}).get('frac'), (v.get('roofline') or {}).get('traffic'), (v.get('roofline_prefill') or {}).get('achieved')) for k, v in d.get('extra_configs', {}).items()]";;
+pmcprefillfetch)
+  (cd /tmp && rm -rf /tmp/pmc_pf_fetch && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_pf_fetch -o pf -- python $REPO/tools/prefill_bench.py > $OUT/prefill_under_pmc_fetch.json 2> $OUT/prefill_pmc_fetch.err; echo "pmcprefillfetch rc=$?")
+  f=$(find /tmp/pmc_pf_fetch -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_prefill_fetch.py $f $OUT/prefill_pmc_fetch_summary.json | tail -40;;
+prefillbench)
+  timeout 600 python tools/prefill_bench.py > $OUT/prefill_bench.json 2> $OUT/prefill_bench.err; echo "prefill rc=$?"; cat $OUT/prefill_bench.json;;
 *) echo "unknown step $w";;
 esac
 done
