@@ -124,7 +124,7 @@ pmcg)
 tp3)
   timeout 1500 python -m pytest tests -m gpu -q -rf -s -k "tp or cpu_oracle or fp8_kv_store or rccl or p2p" --durations=8 > $OUT/pytest_tp3.log 2>&1; echo "tp3 pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|argmax|device-resident" $OUT/pytest_tp3.log | tail -30;;
 benchfull)
-  T0=$(date +%s); timeout 1500 python bench.py > $OUT/bench_full.json 2> $OUT/bench_full.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"; tail -c 400 $OUT/bench_full.err; python -c "
+  T0=$(date +%s); timeout 1500 python bench.py ${BENCH_ARGS:-} > $OUT/bench_full.json 2> $OUT/bench_full.err; echo "bench rc=$? wall=$(( $(date +%s) - T0 )) s"; tail -c 400 $OUT/bench_full.err; python -c "
 import json; d=json.load(open('$OUT/bench_full.json')); print(round(d['value']), d['roofline']['frac'], d['roofline']['decode_step']['frac_of_8TBps'], d.get('cpu_baseline')); [print(k, v.get('value'), v.get('error'), v.get('wall_s_incl_engine_start'), (v.get('roofline') or {}).get('frac'), (v.get('roofline') or {}).get('traffic'), (v.get('roofline_prefill') or {}).get('achieved')) for k, v in d.get('extra_configs', {}).items()]";;
 pmcprefillfetch)
   (cd /tmp && rm -rf /tmp/pmc_pf_fetch && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_pf_fetch -o pf -- python $REPO/tools/prefill_bench.py > $OUT/prefill_under_pmc_fetch.json 2> $OUT/prefill_pmc_fetch.err; echo "pmcprefillfetch rc=$?")
