@@ -59,6 +59,8 @@ enum { EPI_BF16 = 0, EPI_SILU = 1, EPI_PARTIAL = 2 };
 
 __device__ __forceinline__ float silu_f32(float g) { return g / (1.f + __expf(-g)); }
 
+__host__ __device__ constexpr int wide_stages(int mt) { return 3 * mt * 16 * 256 <= 144 * 1024 ? 3 : 2; }
+
 template <int MT, int NT, int NW, int EPI, int RING, bool PACKED>
 __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
                                                                      const bf16_t* __restrict__ w,
@@ -66,6 +68,10 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
                                                                      int steps, int paired_tiles) {
   constexpr int kRows = MT * 16;
   constexpr int kStage = kRows * 256;                             // bytes per LDS stage
+  // x stages: three (the loader runs two steps ahead) while they fit the 160 KiB of LDS — up to 12 row tiles; two (one
+  // step ahead) for 13-16 row tiles, the single-row-group form for 145-256 rows
+  constexpr int NS = wide_stages(MT);
+  constexpr int AHEAD = NS - 1;
   static_assert(EPI != EPI_SILU || NT == 2, "SiLU: a wave holds a gate tile and its up tile");
   constexpr int GT = EPI == EPI_SILU ? 1 : NT;                    // output tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,7 +111,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
     // l15 of row r holds chunk l15 ^ (r & 15)), so an instruction still reads 4 rows x 256 contiguous bytes.
     // The loads are inline asm (hipcc neither counts them nor keeps M0), so this wave's waits are explicit.
     constexpr int kLC = MT * 4;
-    static_assert(kLC < 64, "vmcnt is a 6-bit counter");
+    static_assert(kLC * (AHEAD - 1) < 64, "vmcnt is a 6-bit counter");
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const bf16_t* xb = x + k0;
     int x_src[kLC];                                               // element offsets (M * K < 2^31)
@@ -117,7 +123,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
       x_src[i] = grow * K + ((l15 ^ (row & 15)) << 3);
     }
     auto issue = [&](int s) {
-      const unsigned dst = lds0 + (unsigned)(s % 3) * kStage;
+      const unsigned dst = lds0 + (unsigned)(s % NS) * kStage;
       const bf16_t* src = xb + kstep(s) * kBK;
 #pragma unroll
       for (int i = 0; i < kLC; ++i) {
@@ -129,19 +135,20 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
                      : "memory");
       }
     };
+    // AHEAD steps in flight; "step s + 1 has landed" = at most the newest AHEAD - 1 steps' loads are still outstanding
     issue(0);
-    if (steps > 1) {
+    if (AHEAD > 1 && steps > 1) {
       issue(1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC) : "memory");   // step 0 has landed
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC * (AHEAD - 1)) : "memory");   // step 0 has landed
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < steps; ++s) {
-      // stage (s + 2) % 3 was last read during step s - 1: free since the previous barrier
-      if (s + 2 <= last) {
-        issue(s + 2);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC) : "memory"); // step s + 1 has landed
+      // stage (s + AHEAD) % NS was last read during step s - 1: free since the previous barrier
+      if (s + AHEAD <= last) {
+        issue(s + AHEAD);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC * (AHEAD - 1)) : "memory"); // step s + 1 has landed
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -267,7 +274,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
     for (int i = 0; i < RING; ++i) {
       const int s = blk * RING + i;
       // the weights RING - 1 steps ahead are requested inside compute()
-      compute(std::true_type{}, smem + (s % 3) * kStage, wf[i], wf[(i + RING - 1) % RING], s + RING - 1);
+      compute(std::true_type{}, smem + (s % NS) * kStage, wf[i], wf[(i + RING - 1) % RING], s + RING - 1);
       __syncthreads();                                            // stage (s + 1) % 3 is staged, stage s % 3 is free
     }
   }
@@ -275,7 +282,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
   for (int i = 0; i < RING - 1; ++i) {
     const int s = nblk * RING + i;
     if (s < steps) {
-      compute(std::false_type{}, smem + (s % 3) * kStage, wf[i], nullptr, 0);
+      compute(std::false_type{}, smem + (s % NS) * kStage, wf[i], nullptr, 0);
       __syncthreads();
     }
   }
@@ -354,7 +361,9 @@ struct WidePlan {
 // Weight ring depth. 5 waves (NW = 4) share 4 SIMDs, so those kernels live in 256 registers: one set less at 7+ row
 // tiles x 2 column tiles.
 constexpr int ring_of(int nt, int nw, int mt) {
-  if (nw == 3) return nt == 1 ? 8 : 6;          // 4 waves, one per SIMD: 512 registers per wave
+  if (nw == 3) return nt == 1 ? 8 : (mt > 9 ? 4 : 6);   // 4 waves, one per SIMD: 512 registers per wave
+  if (mt > 9) return mt == 12 ? 3 : 4;                  // (only NT = 1 is instantiated above 9 row tiles with 5 waves; 12 row
+                                                        //  tiles keep three x stages and spill with a deeper ring)
   return nt == 1 ? 6 : (mt >= 7 ? 3 : 4);
 }
 
@@ -365,7 +374,7 @@ int env_int(const char* name, int dflt) {
 
 // Row-tile counts that are instantiated (a batch is rounded up to the next one; the x rows past M are clamped reads)
 int round_mt(int mtiles, int nt) {
-  static const int kMT[] = {1, 2, 3, 5, 7, 9};
+  static const int kMT[] = {1, 2, 3, 5, 7, 9, 12, 16};
   for (int c : kMT)
     if (c >= mtiles) return c;
   return 0;
@@ -383,7 +392,8 @@ double wide_cost(int64_t m, int n, int k, int mode, const WidePlan& p) {
   const double wbytes_step = (double)p.nw * p.nt * 16 * 256.0;
   const double t_w = wbytes_step / 28.0e3;                                        // us at 28 GB/s per CU
   const double t_mfma = (double)p.mt * p.nt * kKB * 16.0 / 2400.0;               // 16 clk per MFMA at 2.4 GHz
-  const double t_x = (double)p.mt * 16 * 256.0 / 67.0e3;                          // L2 -> LDS staging of the x tile
+  double t_x = (double)p.mt * 16 * 256.0 / 67.0e3;                                // L2 -> LDS staging of the x tile
+  if (wide_stages(p.mt) == 2 && t_x < 1.1) t_x = 1.1;                            // one step ahead only: an L2 round trip per step
   double t_step = t_w;
   if (t_mfma > t_step) t_step = t_mfma;
   if (t_x > t_step) t_step = t_x;
@@ -417,25 +427,30 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
     if (mode == EPI_SILU && nt == 1) continue;
     for (int nw : {4, 3}) {
       if (force_nw && nw != force_nw) continue;
-      WidePlan p;
-      p.nt = nt;
-      p.nw = nw;
-      // <= 9 row tiles per row group (accumulators + weight ring + fragments in the register file); more rows = more
-      // row groups (grid.z), whose workgroups run side by side and share the weight stream through L2 / MALL
-      const int mt_max = 9;
-      p.mgroups = (mtiles + mt_max - 1) / mt_max;
-      p.mt = round_mt((mtiles + p.mgroups - 1) / p.mgroups, nt);
-      if (!p.mt) continue;
-      const int cols = nw * (mode == EPI_SILU ? 1 : nt) * 16;
-      p.tiles = (out_cols + cols - 1) / cols;
-      for (int split = 1; split <= 32; ++split) {
-        if (ksteps % split) continue;
-        if (force_split && split != force_split) continue;
-        if (split > 1 && ksteps / split < 2) break;
-        p.split = split;
-        p.steps = ksteps / split;
-        const double t = wide_cost(m, n, k, mode, p);
-        if (t < best_t) { best_t = t; *best = p; }
+      // Row tiles per row group: <= 9 everywhere; 10-16 (ONE row group up to 256 rows: every weight byte is streamed
+      // once, where two groups stream it twice) only in the decompositions whose register file holds 16 row tiles of
+      // accumulators next to the weight ring — 4 waves with one SIMD each (NW = 3), or one column tile per wave.
+      // More rows = more row groups, whose workgroups are paired on one XCD (see the kernel).
+      const bool big_ok = (nw == 3 || nt == 1) && env_int("NVL_WIDE_BIG_MT", 1) != 0;
+      for (int mt_max : {16, 9}) {
+        if (mt_max > 9 && (!big_ok || mtiles <= 9)) continue;
+        WidePlan p;
+        p.nt = nt;
+        p.nw = nw;
+        p.mgroups = (mtiles + mt_max - 1) / mt_max;
+        p.mt = round_mt((mtiles + p.mgroups - 1) / p.mgroups, nt);
+        if (!p.mt || (p.mt > 9 && !big_ok)) continue;
+        const int cols = nw * (mode == EPI_SILU ? 1 : nt) * 16;
+        p.tiles = (out_cols + cols - 1) / cols;
+        for (int split = 1; split <= 32; ++split) {
+          if (ksteps % split) continue;
+          if (force_split && split != force_split) continue;
+          if (split > 1 && ksteps / split < 2) break;
+          p.split = split;
+          p.steps = ksteps / split;
+          const double t = wide_cost(m, n, k, mode, p);
+          if (t < best_t) { best_t = t; *best = p; }
+        }
       }
     }
   }
@@ -449,7 +464,7 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
 template <int MT, int NT, int NW, int EPI, bool PACKED>
 int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
   constexpr int RING = ring_of(NT, NW, MT);
-  const size_t lds = (size_t)3 * MT * 16 * 256;
+  const size_t lds = (size_t)wide_stages(MT) * MT * 16 * 256;
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set && lds > 64 * 1024) {
@@ -490,6 +505,12 @@ int dispatch_mt(const WidePlan& p, const void* x, const void* w, void* out, int6
     case 5: return launch_wide<5, NT, NW, EPI>(p, x, w, out, m, n, k, s);
     case 7: return launch_wide<7, NT, NW, EPI>(p, x, w, out, m, n, k, s);
     case 9: return launch_wide<9, NT, NW, EPI>(p, x, w, out, m, n, k, s);
+  }
+  if constexpr (NW == 3 || NT == 1) {
+    switch (p.mt) {
+      case 12: return launch_wide<12, NT, NW, EPI>(p, x, w, out, m, n, k, s);
+      case 16: return launch_wide<16, NT, NW, EPI>(p, x, w, out, m, n, k, s);
+    }
   }
   nvl_set_error("nvl_linear_wide: internal plan error (mt=%d nt=%d nw=%d)", p.mt, p.nt, p.nw);
   return NVL_EINVAL;
