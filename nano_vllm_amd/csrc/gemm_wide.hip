@@ -61,8 +61,17 @@ __device__ __forceinline__ float silu_f32(float g) { return g / (1.f + __expf(-g
 
 __host__ __device__ constexpr int wide_stages(int mt) { return 3 * mt * 16 * 256 <= 144 * 1024 ? 3 : 2; }
 
+// Loader waves per workgroup. One wave keeps at most 63 loads (63 KiB of 1-KiB LDS-DMA instructions) in flight — the
+// vmcnt counter is 6 bits — which at the L2 latency seen under load is ~30 GB/s: in the x-heavy decompositions (few
+// columns per workgroup, many rows) staging the x tile, not streaming the weights, set the step time
+// (profiles/r03_gemm_wide_sweep_m144.jsonl: 36 KiB of x per 1.2-1.3 us whatever the weight bytes). The 5-wave
+// configurations (NW = 4: <= 256 registers per wave, so a sixth wave fits a SIMD next to a consumer) take TWO loader
+// waves, each staging every other 1-KiB piece of the tile; the 4-wave ones (NW = 3) own their SIMD's whole register
+// file and cannot host another wave.
+__host__ __device__ constexpr int wide_loaders(int nw) { return nw == 4 ? 2 : 1; }
+
 template <int MT, int NT, int NW, int EPI, int RING, bool PACKED>
-__global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
+__global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
                                                                      const bf16_t* __restrict__ w,
                                                                      void* __restrict__ out, int M, int N, int K,
                                                                      int steps, int paired_tiles) {
@@ -102,33 +111,35 @@ __global__ __launch_bounds__((NW + 1) * 64) void linear_wide_kernel(const bf16_t
     return s >= steps ? s - steps : s;
   };
 
-  if (wave == NW) {
-    // ---- loader wave: x tile of step s + 2 -> LDS stage (s + 2) % 3 while the consumers work on step s -----------
+  if (wave >= NW) {
+    // ---- loader wave(s): x tile of step s + 2 -> LDS stage (s + 2) % 3 while the consumers work on step s --------
     // LDS-DMA (global_load_lds_dwordx4: 64 lanes x 16 B land at M0 + 16 lane, no staging registers), two steps in
     // flight: staging a step is one L2 round trip long, and with a single step in flight that round trip was the
     // step time of the whole workgroup (first loader version: 1.7 us per step at 16 rows). Instruction i covers
     // LDS chunks 64 i .. 64 i + 63 = rows 4 i + lq, slots l15; the XOR swizzle is applied on the SOURCE side (slot
     // l15 of row r holds chunk l15 ^ (r & 15)), so an instruction still reads 4 rows x 256 contiguous bytes.
     // The loads are inline asm (hipcc neither counts them nor keeps M0), so this wave's waits are explicit.
-    constexpr int kLC = MT * 4;
-    static_assert(kLC * (AHEAD - 1) < 64, "vmcnt is a 6-bit counter");
+    constexpr int NL = wide_loaders(NW);
+    constexpr int kLC = MT * 4 / NL;                              // 1-KiB pieces of a tile staged by THIS loader wave
+    static_assert((MT * 4) % NL == 0 && kLC * (AHEAD - 1) < 64, "vmcnt is a 6-bit counter");
+    const int lw = wave - NW;                                     // which loader: pieces lw, lw + NL, ...
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const bf16_t* xb = x + k0;
     int x_src[kLC];                                               // element offsets (M * K < 2^31)
 #pragma unroll
     for (int i = 0; i < kLC; ++i) {
-      const int row = 4 * i + lq;
+      const int row = 4 * (i * NL + lw) + lq;
       int grow = m_base + row;
       grow = grow < M ? grow : M - 1;                             // padding rows read a valid row (never stored)
       x_src[i] = grow * K + ((l15 ^ (row & 15)) << 3);
     }
     auto issue = [&](int s) {
-      const unsigned dst = lds0 + (unsigned)(s % NS) * kStage;
+      const unsigned dst = lds0 + (unsigned)(s % NS) * kStage + (unsigned)lw * 1024;
       const bf16_t* src = xb + kstep(s) * kBK;
 #pragma unroll
       for (int i = 0; i < kLC; ++i) {
         unsigned keep;
-        const unsigned d = __builtin_amdgcn_readfirstlane(dst + i * 1024);
+        const unsigned d = __builtin_amdgcn_readfirstlane(dst + i * (NL * 1024));
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
                      : "v"(src + x_src[i]), "s"(d)
@@ -479,12 +490,12 @@ int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, in
   static const bool pair_ok = env_int("NVL_WIDE_PAIR", 1) != 0;
   if (p.mgroups == 2 && pair_ok) {
     const unsigned gx = (unsigned)((p.tiles + 7) / 8) * 16;
-    hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>), dim3(gx, p.split, 1), dim3((NW + 1) * 64),
-                       lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, p.tiles);
+    hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>), dim3(gx, p.split, 1),
+                       dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, p.tiles);
     return NVL_OK;
   }
   hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>), dim3(p.tiles, p.split, p.mgroups),
-                     dim3((NW + 1) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, 0);
+                     dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, 0);
   return NVL_OK;
 }
 

@@ -342,14 +342,15 @@ def _decode_sized(x: torch.Tensor) -> bool:
 # width or per-rank): the wide-tile streaming kernel (nvl_linear_wide) on the module's tile-packed weight copy, by a
 # DETERMINISTIC rule read off the measurements on MI355X (profiles/r03_gemm_wide_packed_vs_rowmajor.json: ours / hipBLASLt
 # at 16 / 64 / 144 / 256 rows for every Qwen3-8B, 32B, 32B/TP4 and 32B/TP8 projection): with one row group (<= 144 rows)
-# it is faster than the library GEMM on all but two of the 48 (shape, rows) pairs (each within 2.4 us); with two row
-# groups (145-288 rows) the two workgroups of a column tile share its weight stream through one XCD's L2 (paired
-# dispatch, gemm_wide.hip) and win while the matrix is moderate — <= 140 MB for bf16 / SiLU outputs, <= 90 MB for
-# split-K slab outputs (profiles/r03_gemm_wide_m256_paired.json). The same shapes therefore take the same kernel —
-# hence the same bf16 rounding — in every run.
+# it is faster than the library GEMM on all but two of the 48 (shape, rows) pairs (each within 2.4 us); at 145-256 rows
+# (one row group of 12 / 16 row tiles, or two paired ones: gemm_wide.hip) it wins on every bf16 and slab-output shape
+# measured (32B down at 256 rows: 130 vs 264 us) and on SiLU outputs while the matrix is moderate (<= 140 MB: the
+# per-rank gate_up shapes; the full-width 8B / 32B gate_up stay on the library, 72.7 vs 67.6 and 240 vs 152 us) —
+# profiles/r03_gemm_wide_m200_m256.json. The same shapes therefore take the same kernel — hence the same bf16
+# rounding — in every run.
 # NVL_GEMM_WIDE=0 never uses it, =1 always (whenever the plan covers the shape), =tune decides by timing both once per
 # (rows, n, k, mode) the first time the shape is seen outside a graph capture (a new device / shape family).
-_WIDE_TWO_GROUP_MAX_BYTES = {0: 140e6, 1: 140e6, 2: 90e6}      # by ops.LINEAR_* mode
+_WIDE_MAX_BYTES_ABOVE_144_ROWS = {0: float("inf"), 1: 140e6, 2: float("inf")}      # by ops.LINEAR_* mode
 _wide_choice: dict[tuple, bool] = {}
 _wide_scratch: dict[tuple, torch.Tensor] = {}
 _flush: dict[int, torch.Tensor] = {}
@@ -410,7 +411,7 @@ def _use_wide(x: torch.Tensor, weight: torch.Tensor, mode: int, packed: torch.Te
     elif policy == "1":
         c = True
     elif policy != "tune":
-        c = m <= 144 or (m <= 288 and n * k * 2 <= _WIDE_TWO_GROUP_MAX_BYTES[mode])
+        c = m <= 144 or (m <= 256 and n * k * 2 <= _WIDE_MAX_BYTES_ABOVE_144_ROWS[mode])
     elif torch.cuda.is_current_stream_capturing():
         return False                                   # an untimed shape inside a capture: library GEMM, not cached
     else:

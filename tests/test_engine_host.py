@@ -324,8 +324,9 @@ def test_decode_gemm_chooser_policies(monkeypatch):
     assert layers.decode_linear(xd, deep, ops.LINEAR_BF16) == "wide"                        # 16 rows: one row group
     x200 = torch.zeros(200, 4096)
     assert layers.decode_linear(x200, deep, ops.LINEAR_BF16) == "wide"                      # two row groups, small matrix
-    huge = torch.zeros(20480, 4096)                                                         # 168 MB: library GEMM
-    assert layers.decode_linear(x200, huge, ops.LINEAR_BF16) is None
+    huge = torch.zeros(20480, 4096)                                                         # 168 MB gate|up: library GEMM
+    assert layers.decode_linear(x200, huge, ops.LINEAR_SILU) is None
+    assert layers.decode_linear(x200, huge, ops.LINEAR_BF16) == "wide"
     # tune: timed outside a capture, deferred (not cached) inside one
     layers._wide_choice.clear()
     monkeypatch.setenv("NVL_GEMM_WIDE", "tune")
