@@ -14,12 +14,13 @@
 //     to match the S^T accumulator layout, so P never moves between lanes.
 //   * online softmax in fp32 (base-2), P rounded to bf16 before P.V, fp32 accumulation.
 //   * K/V tiles are double-buffered in LDS and staged through registers with the issue-early /
-//     write-late split (cdna_hip_programming.md T14): the global loads of tile t+1 are issued before
+//     write-late split (cdna_hip_programming.md T14): the global loads of tile t+1 are issued after
 //     the QK^T of tile t and written to the other LDS buffer after its P.V, so HBM/L2 latency hides
-//     under the MFMA phases and there is ONE workgroup barrier per tile.
+//     under the softmax / P.V phase and there is ONE workgroup barrier per tile.
 //   * a wave skips the MFMA work of key tiles that lie entirely above its 32 rows' causal frontier.
-// The (sequence, q-block) of a workgroup is found on device from cu_seqlens_q (prefix sum in
-// LDS + binary search), so no host-side tile list is needed.
+// The (sequence, q-block) of a workgroup is found on device from cu_seqlens_q — in registers (shuffle scan + ballot +
+// readlane, one global round trip, no barrier) for launches of up to 64 sequences, through an LDS prefix + binary
+// search beyond that — so no host-side tile list is needed.
 #include "common.h"
 #include <stdlib.h>
 
@@ -65,8 +66,60 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   const int hsub = wave_all >> 2;                       // which of the workgroup's q-heads (NW == 8)
   const int qcol = lane & 31, hi = lane >> 5;
 
+  // Longest-first dispatch: workgroups are launched in block-id order and a q-block's work grows with its
+  // index (causal), so tiles are taken from the END of the list and the head index varies fastest — the
+  // short tiles fill the tail instead of the 64-tile ones (measured 1.2-1.4x on 4 x 4096 / 1 x 16384). (A batch-wide
+  // longest-first order — every sequence's top block, then every next one — was measured too: +6 % at 16 x 1024 but
+  // -4 % on ragged bench batches and -10 % at 8 x 2048 / G = 8: neighbouring workgroups then stream DIFFERENT sequences'
+  // K/V and the working set of the workgroups in flight outgrows the L2s. profiles/r03_prefill_ab_s1_l{4,0}.json.)
+  // Which (q-head, tile)? The G = hq / hkv query heads of a kv group stream the SAME K/V tiles. MI355X has 8 XCDs
+  // with private L2s and hands workgroup b to XCD b % 8, so with the plain order (head fastest) the heads of a
+  // group land on G different XCDs and every one of them pulls the tiles through its own L2. xcd_map: workgroups
+  // are numbered so that the G heads of a (tile, kv-head) group occupy CONSECUTIVE slots of ONE XCD — they run
+  // side by side at the same pace and all but the first hit that XCD's L2 (cdna_hip_programming.md T1; placement
+  // only changes speed, never results).
+  int head, tile_rank;
+  if (xcd_map) {
+    const int G = hq / hkv;
+    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int gi = slot / G, g = slot - gi * G;
+    const int j = gi * 8 + xcd;                    // (tile, kv-head) group, longest tiles first
+    tile_rank = j / hkv;
+    head = (j - tile_rank * hkv) * G + g;
+  } else {
+    head = NW == 8 ? blockIdx.x * 2 + hsub : blockIdx.x;
+    tile_rank = blockIdx.y;
+  }
   // ---- which (sequence, q-block) is this workgroup? ------------------------------------
-  {
+  int seq, qblk, q0, lq, k0, lk;     // wave-uniform
+  if (num_seqs <= 64) {
+    // Up to 64 sequences (every prefill batch of the bench): each WAVE derives the tile list by itself, in
+    // registers — lane i holds sequence i's cu_seqlens entries, a shuffle scan gives the tile prefix, a ballot finds
+    // the sequence, readlane fetches its bounds. One global round trip, no LDS, no workgroup barrier, no dependent
+    // re-load of cu_seqlens[seq] (the LDS form below costs three barriers, a binary search out of LDS and a second
+    // dependent round trip per workgroup: ~1 us of a short sequence's ~5 us workgroup).
+    int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (lane < num_seqs) {
+      a0 = cu_q[lane]; a1 = cu_q[lane + 1];
+      b0 = cu_k[lane]; b1 = cu_k[lane + 1];
+    }
+    const int val = (a1 - a0 + kQBlk - 1) / kQBlk;
+    int sc = val;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int n = __shfl_up(sc, o, 64);
+      if (lane >= o) sc += n;
+    }
+    const int total = __builtin_amdgcn_readlane(sc, 63);
+    if (tile_rank >= total) return;  // grid is an upper bound
+    const int tile = total - 1 - tile_rank;        // longest-first, see above
+    seq = __popcll(__ballot(sc <= tile));          // inclusive prefixes <= tile: the sequences before ours
+    qblk = tile - __builtin_amdgcn_readlane(sc - val, seq);
+    q0 = __builtin_amdgcn_readlane(a0, seq);
+    lq = __builtin_amdgcn_readlane(a1, seq) - q0;
+    k0 = __builtin_amdgcn_readlane(b0, seq);
+    lk = __builtin_amdgcn_readlane(b1, seq) - k0;
+  } else {
     int carry = 0;
     if (tid == 0) pre[0] = 0;
     for (int base = 0; base < num_seqs; base += NT) {
@@ -92,44 +145,23 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
       carry += tot;
       __syncthreads();
     }
+    __syncthreads();
+    if (tile_rank >= pre[num_seqs]) return;  // grid is an upper bound
+    const int tile = pre[num_seqs] - 1 - tile_rank;
+    int lo = 0, hi_s = num_seqs;
+    while (hi_s - lo > 1) {
+      const int mid = (lo + hi_s) >> 1;
+      if (pre[mid] <= tile) lo = mid; else hi_s = mid;
+    }
+    // wave-uniform by construction, but read out of LDS: tell the compiler (scalar registers, scalar loads of
+    // cu_seqlens / block tables, SGPR-based K/V addressing whose VGPR offsets stay live across the loop)
+    seq = __builtin_amdgcn_readfirstlane(lo);
+    qblk = __builtin_amdgcn_readfirstlane(tile - pre[seq]);
+    q0 = cu_q[seq]; lq = cu_q[seq + 1] - q0;
+    k0 = cu_k[seq]; lk = cu_k[seq + 1] - k0;
   }
-  __syncthreads();
-  // Longest-first dispatch: workgroups are launched in block-id order and a q-block's work grows with its
-  // index (causal), so tiles are taken from the END of the list and the head index varies fastest — the
-  // short tiles fill the tail instead of the 64-tile ones (measured 1.2-1.4x on 4 x 4096 / 1 x 16384).
-  // Which (q-head, tile)? The G = hq / hkv query heads of a kv group stream the SAME K/V tiles. MI355X has 8 XCDs
-  // with private L2s and hands workgroup b to XCD b % 8, so with the plain order (head fastest) the heads of a
-  // group land on G different XCDs and every one of them pulls the tiles through its own L2. xcd_map: workgroups
-  // are numbered so that the G heads of a (tile, kv-head) group occupy CONSECUTIVE slots of ONE XCD — they run
-  // side by side at the same pace and all but the first hit that XCD's L2 (cdna_hip_programming.md T1; placement
-  // only changes speed, never results).
-  int head, tile_rank;
-  if (xcd_map) {
-    const int G = hq / hkv;
-    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
-    const int gi = slot / G, g = slot - gi * G;
-    const int j = gi * 8 + xcd;                    // (tile, kv-head) group, longest tiles first
-    tile_rank = j / hkv;
-    head = (j - tile_rank * hkv) * G + g;
-  } else {
-    head = NW == 8 ? blockIdx.x * 2 + hsub : blockIdx.x;
-    tile_rank = blockIdx.y;
-  }
-  if (tile_rank >= pre[num_seqs]) return;  // grid is an upper bound
-  const int tile = pre[num_seqs] - 1 - tile_rank;
-  int lo = 0, hi_s = num_seqs;
-  while (hi_s - lo > 1) {
-    const int mid = (lo + hi_s) >> 1;
-    if (pre[mid] <= tile) lo = mid; else hi_s = mid;
-  }
-  // wave-uniform by construction, but read out of LDS: tell the compiler (scalar registers, scalar loads of
-  // cu_seqlens / block tables, SGPR-based K/V addressing whose VGPR offsets stay live across the loop)
-  const int seq = __builtin_amdgcn_readfirstlane(lo);
-  const int qblk = __builtin_amdgcn_readfirstlane(tile - pre[seq]);
   const int kvh = head / (hq / hkv);
 
-  const int q0 = cu_q[seq], lq = cu_q[seq + 1] - q0;
-  const int k0 = cu_k[seq], lk = cu_k[seq + 1] - k0;
   const int off = lk - lq;  // bottom-right alignment: query i sees keys j <= i + off
   const int qi = qblk * kQBlk + wave * 32 + qcol;
   const bool q_valid = qi < lq;
@@ -246,14 +278,26 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     }
   };
   // keys this WAVE's 32 rows can see: tiles starting above wave_kmax carry no work for it
-  const int wave_kmax = min(qblk * kQBlk + wave * 32 + 31, lq - 1) + off;
+  // (a wave whose 32 rows all lie past the end of the sequence — the tail of the last q-block — has no work at all:
+  // it only helps staging the tiles; +3-4 % on batches of short sequences)
+  const bool wave_has_rows = qblk * kQBlk + wave * 32 < lq;
+  const int wave_kmax = wave_has_rows ? min(qblk * kQBlk + wave * 32 + 31, lq - 1) + off : -1;
   const int wave_kmin = min(qblk * kQBlk + wave * 32, lq - 1) + off;   // ... and all of them see keys <= wave_kmin
 
-  if (kv_end > 0) {
-    stage_load(0);
-    stage_write(0);
-  }
+  // kv_end >= 1 always (lq >= 1, off >= 0): unconditional, with an explicit vmcnt(0) — hipcc's waitcnt pass then KNOWS
+  // the Q fragment loads have landed before the loop (with a conditional prologue it assumes they may be pending at the
+  // loop head and puts vmcnt waits on their first uses inside QK^T, which drain whatever tile loads are in flight).
+  stage_load(0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
+  // a (no-op) use of the Q fragments HERE: without it LLVM sinks their loads into the loop preheader, behind this wait
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) asm volatile("" : "+v"(qf[ds]));
+  stage_write(0);
   __syncthreads();
+
+  // wave-uniform copies on the scalar side (scalar branches instead of exec masks)
+  const int wave_kmax_s = __builtin_amdgcn_readfirstlane(wave_kmax);
+  const int wave_kmin_s = __builtin_amdgcn_readfirstlane(wave_kmin);
 
   int buf = 0;
   for (int kt = 0; kt < kv_end; kt += kKBlk, buf ^= 1) {
@@ -261,87 +305,101 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     const unsigned char* k_lds = smem + buf * kTileBytes;
     const unsigned char* v_lds = k_lds + kKBlk * kKRowB;
     // ---- S^T tile: 2 key blocks x 32 keys; lane = query column ---------------------------------
-    f32x16_t sacc[2] = {kZero16, kZero16};
-    if (kt <= wave_kmax) {
+    auto qk = [&](f32x16_t (&sacc)[2]) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      // A operand: lane (key row kb*32 + qcol, hi) holds d = ds*16 + 8*hi .. +8 (swizzled 16-byte slot)
-      const unsigned char* kr = k_lds + kb * 32 * kKRowB;
-      sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-          as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[0])), qf[0], kZero16, 0, 0, 0);
-#pragma unroll
-      for (int ds = 1; ds < 8; ++ds)
+      for (int kb = 0; kb < 2; ++kb) {
+        // A operand: lane (key row kb*32 + qcol, hi) holds d = ds*16 + 8*hi .. +8 (swizzled 16-byte slot)
+        const unsigned char* kr = k_lds + kb * 32 * kKRowB;
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[ds])), qf[ds], sacc[kb], 0, 0, 0);
-    }
-    }  // kt <= wave_kmax (QK^T)
-    // next tile's loads: issued after QK^T (hipcc's waitcnt pass otherwise drains them inside it), in
-    // flight under the softmax and the P.V MFMAs
-    __builtin_amdgcn_sched_barrier(0);
-    if (more) stage_load(kt + kKBlk);
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt <= wave_kmax) {
-    // ---- online softmax (base 2; the softmax scale is folded into the exponent's FMA) --------------
-    // Only tiles that straddle this wave's causal frontier need the per-element mask.
-    if (kt + kKBlk - 1 > wave_kmin) {
+            as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[0])), qf[0], kZero16, 0, 0, 0);
+#pragma unroll
+        for (int ds = 1; ds < 8; ++ds)
+          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[ds])), qf[ds], sacc[kb], 0, 0, 0);
+      }
+      // K fragment reads pinned three ahead of their MFMA (16 ds_read_b128, 16 MFMAs)
+      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    };
+    auto softmax_pv = [&](f32x16_t (&sacc)[2], int kmin_w) {
+      // ---- online softmax (base 2; the softmax scale is folded into the exponent's FMA) --------------
+      // Only tiles that straddle this wave's causal frontier need the per-element mask.
+      if (kt + kKBlk - 1 > kmin_w) {
+        // key(kb, r) = kt + 4 hi + c, c = kb*32 + (r & 3) + 8 (r >> 2) a compile-time constant: one subtraction, then a
+        // compare-with-immediate + select per score
+        const int lim = kmax_vis - kt - 4 * hi;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            sacc[kb][r] = (kb * 32 + (r & 3) + 8 * (r >> 2)) <= lim ? sacc[kb][r] : kNegBig;
+      }
+      float mx = sacc[0][0];
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          sacc[kb][r] = key <= kmax_vis ? sacc[kb][r] : kNegBig;
-        }
-    }
-    float mx = sacc[0][0];
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx * scale_log2e);
+      if (__any(m_new > m_run)) {          // some row's running max moved: rescale (exact no-op otherwise)
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+        for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx * scale_log2e);
-    if (__any(m_new > m_run)) {          // some row's running max moved: rescale (exact no-op otherwise)
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 4; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-      m_run = m_new;
-    }
-    float psum = 0.f;
-    bf16x8_t pf[2][2];  // [kb][r0]: P^T fragment (B operand), k-slot (hi, e) <-> acc reg r0*8 + e
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r0 = 0; r0 < 2; ++r0)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r0 * 8 + e], scale_log2e, -m_run));
-          psum += p;
-          pf[kb][r0][e] = (bf16_t)p;
-        }
-    l_run += psum;
-
-    // ---- O^T += V^T . P^T : A operand lane (d = lane&31, hi) needs V[key(hi, e)][d] ----------
-    // key(hi, e) = kb*32 + 16*r0 + 4*hi + (e & 3) + 8*(e >> 2): two transpose reads of 4 keys.
-    const unsigned char* vb = v_lds + vlane;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int r0 = 0; r0 < 2; ++r0) {
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          const unsigned char* p0 = vb + (kb * 32 + 16 * r0) * kVRowB + db * 64;   // compile-time offset
-          const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t*)(p0));
-          const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4_t*)(p0 + 8 * kVRowB));
-          const s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[kb][r0], oacc[db],
-                                                             0, 0, 0);
-        }
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        m_run = m_new;
       }
-    }  // kt <= wave_kmax
+      float psum = 0.f;
+      bf16x8_t pf[2][2];  // [kb][r0]: P^T fragment (B operand), k-slot (hi, e) <-> acc reg r0*8 + e
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r0 = 0; r0 < 2; ++r0)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r0 * 8 + e], scale_log2e, -m_run));
+            psum += p;
+            pf[kb][r0][e] = (bf16_t)p;
+          }
+      l_run += psum;
+
+      // ---- O^T += V^T . P^T : A operand lane (d = lane&31, hi) needs V[key(hi, e)][d] ----------
+      // key(hi, e) = kb*32 + 16*r0 + 4*hi + (e & 3) + 8*(e >> 2): two transpose reads of 4 keys.
+      const unsigned char* vb = v_lds + vlane;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r0 = 0; r0 < 2; ++r0) {
+#pragma unroll
+          for (int db = 0; db < 4; ++db) {
+            const unsigned char* p0 = vb + (kb * 32 + 16 * r0) * kVRowB + db * 64;   // compile-time offset
+            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4_t*)(p0));
+            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4_t*)(p0 + 8 * kVRowB));
+            const s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[kb][r0],
+                                                               oacc[db], 0, 0, 0);
+          }
+        }
+    };
+    // QK^T | issue the next tile's loads | softmax + P.V. The score registers are written and read under the same
+    // (scalar) test and deliberately left unset on the skipped path: initialised, hipcc zero-fills all 32 of them at
+    // every loop head (49 moves per tile; this form measured +9-12 % — profiles/r03_prefill_ab_*.json). The loads sit
+    // after QK^T: issued at the top of the iteration (a full tile of latency cover) they measured 1-2 % slower.
+    f32x16_t sacc[2];
+    const bool active = kt <= wave_kmax_s;
+    if (active) qk(sacc);
+    __builtin_amdgcn_sched_barrier(0);
+    if (more) stage_load(kt + kKBlk);
+    __builtin_amdgcn_sched_barrier(0);
+    if (active) softmax_pv(sacc, wave_kmin_s);
     __builtin_amdgcn_sched_barrier(0);
     if (more) stage_write(buf ^ 1);     // the other buffer was last read one barrier ago
     __syncthreads();

@@ -558,6 +558,29 @@ def test_prefill_many_short_sequences(ops):
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
 
 
+@pytest.mark.parametrize("nseq", [1, 63, 64, 65])
+def test_prefill_tile_list_in_registers_and_in_lds(ops, nseq):
+    """Up to 64 sequences a wave derives the (sequence, q-block) of its workgroup in registers (shuffle scan + ballot +
+    readlane), beyond that through the LDS prefix: both sides of the switch, ragged lengths whose last q-block leaves
+    one, two or three of the four waves without rows (those skip the MFMA work), outputs AND softmax LSE vs the oracle."""
+    gen = g(4400 + nseq)
+    lens = torch.randint(1, 300, (nseq,), generator=gen).tolist()
+    lens[0] = 129          # 1 valid row in the second q-block: three idle waves
+    n, hq, hkv = sum(lens), 4, 2
+    q = torch.randn(n, hq, 128, generator=gen).to(BF16)
+    k = torch.randn(n, hkv, 128, generator=gen).to(BF16)
+    v = torch.randn(n, hkv, 128, generator=gen).to(BF16)
+    cu = _cu(lens)
+    scale = 128 ** -0.5
+    o_ref, lse_ref = ref.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, scale, True, None,
+                                                return_softmax_lse=True)
+    lse = torch.empty(n, hq, dtype=torch.float32, device="cuda")
+    o = ops.attn_prefill_varlen(dev(q), dev(k), dev(v), dev(cu), dev(cu), max(lens), scale, lse=lse)
+    err = (o.cpu().float() - o_ref.float()).abs().max().item()
+    assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
+    assert float((lse.cpu() - lse_ref).abs().max()) <= 2e-3
+
+
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1), (32, 8)])
 @pytest.mark.parametrize("lq_lk", [[(1, 257)], [(100, 356), (256, 256), (7, 1031)], [(300, 812), (64, 64)]])
 def test_prefill_paged_prefix(ops, hq, hkv, lq_lk):

@@ -49,6 +49,13 @@ res["relerr"] = float((o.float() - o_ref.float()).abs().max() / o_ref.float().ab
 
 case([1024] * 16, 16, 8, "0.6B 16x1024")
 case([561] * 29, 16, 8, "bench-like 29x561")
+import random
+random.seed(0)
+ragged = []
+while sum(ragged) + 1024 <= 16384:
+    ragged.append(random.randint(100, 1024))
+case(ragged, 16, 8, f"bench ragged U[100,1024] x{len(ragged)}")           # what a prefill step of bench.py looks like
+case([random.randint(100, 180) for _ in range(110)], 16, 8, "110 short U[100,180]")  # > 64 sequences: LDS tile list
 case([4096] * 4, 16, 8, "0.6B 4x4096")
 case([16384], 8, 1, "32B/TP8 1x16384 (config 5)")
 case([16384], 16, 8, "0.6B 1x16384")
