@@ -339,12 +339,18 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
           for (int r = 0; r < 16; ++r)
             sacc[kb][r] = (kb * 32 + (r & 3) + 8 * (r >> 2)) <= lim ? sacc[kb][r] : kNegBig;
       }
-      float mx = sacc[0][0];
+      float mx = sacc[0][0], mx1 = sacc[1][0];   // two chains: half the dependent depth
 #pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      for (int r = 1; r < 16; ++r) {
+        mx = fmaxf(mx, sacc[0][r]);
+        mx1 = fmaxf(mx1, sacc[1][r]);
+      }
+      mx = fmaxf(mx, mx1);
+      {   // the other half-wave holds the same query's other 32 keys: one v_permlane32_swap (VALU) instead of a
+          // ds_bpermute round trip through the LDS in the middle of every tile's dependent chain
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      }
       const float m_new = fmaxf(m_run, mx * scale_log2e);
       if (__any(m_new > m_run)) {          // some row's running max moved: rescale (exact no-op otherwise)
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -355,7 +361,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
           for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
         m_run = m_new;
       }
-      float psum = 0.f;
+      float psum[2] = {0.f, 0.f};
       bf16x8_t pf[2][2];  // [kb][r0]: P^T fragment (B operand), k-slot (hi, e) <-> acc reg r0*8 + e
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
@@ -364,10 +370,10 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r0 * 8 + e], scale_log2e, -m_run));
-            psum += p;
+            psum[kb] += p;
             pf[kb][r0][e] = (bf16_t)p;
           }
-      l_run += psum;
+      l_run += psum[0] + psum[1];
 
       // ---- O^T += V^T . P^T : A operand lane (d = lane&31, hi) needs V[key(hi, e)][d] ----------
       // key(hi, e) = kb*32 + 16*r0 + 4*hi + (e & 3) + 8*(e >> 2): two transpose reads of 4 keys.
@@ -406,24 +412,34 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   }
 
   // ---- epilogue: normalise and store O[query][d] ------------------------------------------------
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  float l_tot;
+  {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(l_run), __float_as_uint(l_run), false, false);
+    l_tot = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+  }
   const float inv = 1.f / l_tot;
   // optional log-sum-exp of the scaled scores per (query, head), natural log (flash-attn's softmax_lse): the running
   // max / sum live in the log2 domain here
   if (lse != nullptr && q_valid && hi == 0) lse[(int64_t)(q0 + qi) * hq + head] = 0.6931471805599453f * (m_run + log2f(l_tot));
-  if (q_valid) {
-    bf16_t* op = out + ((int64_t)(q0 + qi) * hq + head) * 128;
+  // A lane holds d = db*32 + 8*rg + 4*hi + (0..3) of its query row: 8 bytes per (db, rg), the other half-wave the 8
+  // bytes next to them. One v_permlane32_swap per dword trades halves between two neighbouring groups, after which
+  // every lane owns 16 contiguous bytes: 8 dwordx4 stores per lane instead of 16 dwordx2 (cdna_hip_programming.md T21;
+  // the store tail of a short sequence's workgroup is issue-bound).
+  bf16_t* op = out + ((int64_t)(q0 + qi_c) * hq + head) * 128 + 8 * hi;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < 4; ++db)
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        // regs rg*4 .. rg*4+3 are d = db*32 + 8*rg + 4*hi + (0..3): 8 contiguous bytes
-        u32x2_t w;
-        w[0] = pack_bf16x2(oacc[db][rg * 4 + 0] * inv, oacc[db][rg * 4 + 1] * inv);
-        w[1] = pack_bf16x2(oacc[db][rg * 4 + 2] * inv, oacc[db][rg * 4 + 3] * inv);
-        *reinterpret_cast<u32x2_t*>(op + db * 32 + 8 * rg + 4 * hi) = w;
-      }
-  }
+    for (int rp = 0; rp < 2; ++rp) {
+      const int r0 = rp * 8;
+      const unsigned int ax = pack_bf16x2(oacc[db][r0 + 0] * inv, oacc[db][r0 + 1] * inv);
+      const unsigned int ay = pack_bf16x2(oacc[db][r0 + 2] * inv, oacc[db][r0 + 3] * inv);
+      const unsigned int bx = pack_bf16x2(oacc[db][r0 + 4] * inv, oacc[db][r0 + 5] * inv);
+      const unsigned int by = pack_bf16x2(oacc[db][r0 + 6] * inv, oacc[db][r0 + 7] * inv);
+      const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+      // lanes 0-31: [own group 2rp | upper half's group 2rp] = d db*32 + 16 rp + 0..7; lanes 32-63: the next 8
+      if (q_valid) *reinterpret_cast<u32x4_t*>(op + db * 32 + 16 * rp) = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+    }
 }
 
 }  // namespace
