@@ -23,6 +23,7 @@
 // search beyond that — so no host-side tile list is needed.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -160,6 +161,16 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     q0 = cu_q[seq]; lq = cu_q[seq + 1] - q0;
     k0 = cu_k[seq]; lk = cu_k[seq + 1] - k0;
   }
+  // Both branches produce wave-uniform values, but after the merge hipcc no longer KNOWS that: left alone it keeps the
+  // K/V buffer descriptors in VGPRs and wraps every tile load in a readfirstlane "waterfall" loop (~10 instructions
+  // per load, loads serialised — cdna_hip_programming.md T20).
+  seq = __builtin_amdgcn_readfirstlane(seq);
+  qblk = __builtin_amdgcn_readfirstlane(qblk);
+  q0 = __builtin_amdgcn_readfirstlane(q0);
+  lq = __builtin_amdgcn_readfirstlane(lq);
+  k0 = __builtin_amdgcn_readfirstlane(k0);
+  lk = __builtin_amdgcn_readfirstlane(lk);
+  head = __builtin_amdgcn_readfirstlane(head);   // (8-wave shape: derived from the wave id, uniform per wave)
   const int kvh = head / (hq / hkv);
 
   const int off = lk - lq;  // bottom-right alignment: query i sees keys j <= i + off
@@ -299,116 +310,127 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   const int wave_kmax_s = __builtin_amdgcn_readfirstlane(wave_kmax);
   const int wave_kmin_s = __builtin_amdgcn_readfirstlane(wave_kmin);
 
-  int buf = 0;
-  for (int kt = 0; kt < kv_end; kt += kKBlk, buf ^= 1) {
+  // ---- S^T tile: 2 key blocks x 32 keys; lane = query column ---------------------------------
+  auto qk = [&](f32x16_t (&sacc)[2], const unsigned char* k_lds) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      // A operand: lane (key row kb*32 + qcol, hi) holds d = ds*16 + 8*hi .. +8 (swizzled 16-byte slot)
+      const unsigned char* kr = k_lds + kb * 32 * kKRowB;
+      sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+          as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[0])), qf[0], kZero16, 0, 0, 0);
+#pragma unroll
+      for (int ds = 1; ds < 8; ++ds)
+        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+            as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[ds])), qf[ds], sacc[kb], 0, 0, 0);
+    }
+    // K fragment reads pinned three ahead of their MFMA (16 ds_read_b128, 16 MFMAs)
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+    for (int i = 0; i < 13; ++i) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+  };
+  auto softmax_pv = [&](f32x16_t (&sacc)[2], int kmin_w, const int kt, const unsigned char* v_lds) {
+    // ---- online softmax (base 2; the softmax scale is folded into the exponent's FMA) --------------
+    // Only tiles that straddle this wave's causal frontier need the per-element mask.
+    if (kt + kKBlk - 1 > kmin_w) {
+      // key(kb, r) = kt + 4 hi + c, c = kb*32 + (r & 3) + 8 (r >> 2) a compile-time constant: one subtraction, then a
+      // compare-with-immediate + select per score
+      const int lim = kmax_vis - kt - 4 * hi;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          sacc[kb][r] = (kb * 32 + (r & 3) + 8 * (r >> 2)) <= lim ? sacc[kb][r] : kNegBig;
+    }
+    float mx = sacc[0][0], mx1 = sacc[1][0];   // two chains: half the dependent depth
+#pragma unroll
+    for (int r = 1; r < 16; ++r) {
+      mx = fmaxf(mx, sacc[0][r]);
+      mx1 = fmaxf(mx1, sacc[1][r]);
+    }
+    mx = fmaxf(mx, mx1);
+    {   // the other half-wave holds the same query's other 32 keys: one v_permlane32_swap (VALU) instead of a
+        // ds_bpermute round trip through the LDS in the middle of every tile's dependent chain
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+      mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    }
+    const float m_new = fmaxf(m_run, mx * scale_log2e);
+    if (__any(m_new > m_run)) {          // some row's running max moved: rescale (exact no-op otherwise)
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      m_run = m_new;
+    }
+    float psum[2] = {0.f, 0.f};
+    bf16x8_t pf[2][2];  // [kb][r0]: P^T fragment (B operand), k-slot (hi, e) <-> acc reg r0*8 + e
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r0 = 0; r0 < 2; ++r0)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r0 * 8 + e], scale_log2e, -m_run));
+          psum[0] += p;
+          pf[kb][r0][e] = (bf16_t)p;
+        }
+    l_run += psum[0] + psum[1];
+
+    // ---- O^T += V^T . P^T : A operand lane (d = lane&31, hi) needs V[key(hi, e)][d] ----------
+    // key(hi, e) = kb*32 + 16*r0 + 4*hi + (e & 3) + 8*(e >> 2): two transpose reads of 4 keys.
+    const unsigned char* vb = v_lds + vlane;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r0 = 0; r0 < 2; ++r0) {
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+          const unsigned char* p0 = vb + (kb * 32 + 16 * r0) * kVRowB + db * 64;   // compile-time offset
+          const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(p0));
+          const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4_t*)(p0 + 8 * kVRowB));
+          const s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[kb][r0],
+                                                             oacc[db], 0, 0, 0);
+        }
+      }
+  };
+  // One tile step, with the LDS buffer a COMPILE-TIME constant (the loop below is unrolled by the two buffers): every
+  // ds_read / ds_write address is then a loop-invariant lane offset + an immediate, instead of ~25 VALU adds per tile
+  // re-basing them on the buffer of the moment.
+  auto tile_step = [&](auto buf_c, const int kt) {
+    constexpr int buf = decltype(buf_c)::value;
     const bool more = kt + kKBlk < kv_end;
     const unsigned char* k_lds = smem + buf * kTileBytes;
     const unsigned char* v_lds = k_lds + kKBlk * kKRowB;
-    // ---- S^T tile: 2 key blocks x 32 keys; lane = query column ---------------------------------
-    auto qk = [&](f32x16_t (&sacc)[2]) {
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb) {
-        // A operand: lane (key row kb*32 + qcol, hi) holds d = ds*16 + 8*hi .. +8 (swizzled 16-byte slot)
-        const unsigned char* kr = k_lds + kb * 32 * kKRowB;
-        sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-            as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[0])), qf[0], kZero16, 0, 0, 0);
-#pragma unroll
-        for (int ds = 1; ds < 8; ++ds)
-          sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
-              as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[ds])), qf[ds], sacc[kb], 0, 0, 0);
-      }
-      // K fragment reads pinned three ahead of their MFMA (16 ds_read_b128, 16 MFMAs)
-      __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-#pragma unroll
-      for (int i = 0; i < 13; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
-    };
-    auto softmax_pv = [&](f32x16_t (&sacc)[2], int kmin_w) {
-      // ---- online softmax (base 2; the softmax scale is folded into the exponent's FMA) --------------
-      // Only tiles that straddle this wave's causal frontier need the per-element mask.
-      if (kt + kKBlk - 1 > kmin_w) {
-        // key(kb, r) = kt + 4 hi + c, c = kb*32 + (r & 3) + 8 (r >> 2) a compile-time constant: one subtraction, then a
-        // compare-with-immediate + select per score
-        const int lim = kmax_vis - kt - 4 * hi;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            sacc[kb][r] = (kb * 32 + (r & 3) + 8 * (r >> 2)) <= lim ? sacc[kb][r] : kNegBig;
-      }
-      float mx = sacc[0][0], mx1 = sacc[1][0];   // two chains: half the dependent depth
-#pragma unroll
-      for (int r = 1; r < 16; ++r) {
-        mx = fmaxf(mx, sacc[0][r]);
-        mx1 = fmaxf(mx1, sacc[1][r]);
-      }
-      mx = fmaxf(mx, mx1);
-      {   // the other half-wave holds the same query's other 32 keys: one v_permlane32_swap (VALU) instead of a
-          // ds_bpermute round trip through the LDS in the middle of every tile's dependent chain
-        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
-        mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      }
-      const float m_new = fmaxf(m_run, mx * scale_log2e);
-      if (__any(m_new > m_run)) {          // some row's running max moved: rescale (exact no-op otherwise)
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        l_run *= alpha;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-        m_run = m_new;
-      }
-      float psum[2] = {0.f, 0.f};
-      bf16x8_t pf[2][2];  // [kb][r0]: P^T fragment (B operand), k-slot (hi, e) <-> acc reg r0*8 + e
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r0 = 0; r0 < 2; ++r0)
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r0 * 8 + e], scale_log2e, -m_run));
-            psum[kb] += p;
-            pf[kb][r0][e] = (bf16_t)p;
-          }
-      l_run += psum[0] + psum[1];
-
-      // ---- O^T += V^T . P^T : A operand lane (d = lane&31, hi) needs V[key(hi, e)][d] ----------
-      // key(hi, e) = kb*32 + 16*r0 + 4*hi + (e & 3) + 8*(e >> 2): two transpose reads of 4 keys.
-      const unsigned char* vb = v_lds + vlane;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r0 = 0; r0 < 2; ++r0) {
-#pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const unsigned char* p0 = vb + (kb * 32 + 16 * r0) * kVRowB + db * 64;   // compile-time offset
-            const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4_t*)(p0));
-            const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                (__attribute__((address_space(3))) s16x4_t*)(p0 + 8 * kVRowB));
-            const s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[kb][r0],
-                                                               oacc[db], 0, 0, 0);
-          }
-        }
-    };
     // QK^T | issue the next tile's loads | softmax + P.V. The score registers are written and read under the same
     // (scalar) test and deliberately left unset on the skipped path: initialised, hipcc zero-fills all 32 of them at
     // every loop head (49 moves per tile; this form measured +9-12 % — profiles/r03_prefill_ab_*.json). The loads sit
     // after QK^T: issued at the top of the iteration (a full tile of latency cover) they measured 1-2 % slower.
     f32x16_t sacc[2];
     const bool active = kt <= wave_kmax_s;
-    if (active) qk(sacc);
+    if (active) qk(sacc, k_lds);
     __builtin_amdgcn_sched_barrier(0);
     if (more) stage_load(kt + kKBlk);
     __builtin_amdgcn_sched_barrier(0);
-    if (active) softmax_pv(sacc, wave_kmin_s);
+    if (active) softmax_pv(sacc, wave_kmin_s, kt, v_lds);
     __builtin_amdgcn_sched_barrier(0);
     if (more) stage_write(buf ^ 1);     // the other buffer was last read one barrier ago
     __syncthreads();
+  };
+  // (Tried on top of this and dropped: a two-score-tile pipeline — QK^T of tile t+1 beside the softmax of tile t,
+  // cdna_hip_programming.md T15 — with the interleave pinned block by block: 253-255 registers, 4-5 % SLOWER at
+  // 1 x 16,384 than this loop; the rolled loop, 1-3 % slower. profiles/r03_prefill_ab_var{0,1,2}.json.)
+  for (int kt = 0; kt < kv_end; kt += 2 * kKBlk) {
+    tile_step(std::integral_constant<int, 0>{}, kt);
+    if (kt + kKBlk >= kv_end) break;
+    tile_step(std::integral_constant<int, 1>{}, kt + kKBlk);
   }
 
   // ---- epilogue: normalise and store O[query][d] ------------------------------------------------

@@ -1,6 +1,4 @@
-O=$(pwd)/gpurun_out/r03p4; mkdir -p $O; R=$(pwd)
-cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_pf1 -o pf -- python $R/tools/prefill_bench.py > $O/prefill_under_pmc1.json 2> $O/pmc1.err; echo "pmc1 rc=$?"
-f=$(find /tmp/pmc_pf1 -name '*counter_collection.csv' | head -1); python $R/tools/pmc_group_summary.py $f prefill_attn $O/prefill_pmc_waits.json | tail -120
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_LDS_IDX_ACTIVE --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_pf2 -o pf -- python $R/tools/prefill_bench.py > $O/prefill_under_pmc2.json 2> $O/pmc2.err; echo "pmc2 rc=$?"
-f=$(find /tmp/pmc_pf2 -name '*counter_collection.csv' | head -1); python $R/tools/pmc_group_summary.py $f prefill_attn $O/prefill_pmc_active.json | grep -v '"SQ_\|counters\|}' | head -80
+O=gpurun_out/r03p7; mkdir -p $O
+timeout 700 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "prefill" > $O/pytest_prefill.log 2>&1; echo "prefill tests rc=$?"; tail -1 $O/pytest_prefill.log
+timeout 300 python tools/prefill_bench.py > $O/prefill.json 2> $O/prefill.err; echo "rc=$?"; python -c "
+import json;d=json.load(open('$O/prefill.json'));print([(c['name'][:14],c['TFLOPs']) for c in d['cases']], d['relerr'])"
