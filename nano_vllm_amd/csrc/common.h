@@ -116,10 +116,15 @@ __device__ __forceinline__ float half8_allreduce_sum(float v) {
 __device__ __forceinline__ float row16_ror8(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));
 }
+// Sum over the wave, every lane gets the total. All on the VALU: four DPP row rotations inside the 16-lane rows, then
+// v_permlane16_swap / v_permlane32_swap to add rows 0+1 | 2+3 and the two halves. (hipcc lowers a __shfl_xor butterfly
+// to six dependent ds_bpermute_b32 — six LDS round trips, ~0.3 us in the middle of the latency-bound norm kernels.)
 __device__ __forceinline__ float wave_allreduce_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v = row16_allreduce_sum(v);
+  const auto s16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(s16[0]) + __uint_as_float(s16[1]);
+  const auto s32 = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(s32[0]) + __uint_as_float(s32[1]);
 }
 __device__ __forceinline__ float wave_allreduce_max(float v) {
 #pragma unroll

@@ -23,7 +23,7 @@ pmc)
   (cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'decode_' -f csv -d /tmp/pmc_replay -o replay -- python $REPO/tools/attn_replay.py --fused --reps 1 > $OUT/replay_under_pmc.json 2> $OUT/replay_pmc.err; echo "pmc rc=$?")
   python tools/pmc_summary.py /tmp/pmc_replay $OUT/pmc_fetch_summary.json | tail -30;;
 benchprof)
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_bench -o bench -- python $REPO/bench.py --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err; echo "benchprof rc=$?")
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_bench -o bench -- python $REPO/bench.py --no-cpu-baseline --no-extra-configs > $OUT/bench_under_rocprof.json 2> $OUT/bench_prof.err; echo "benchprof rc=$?")
   f=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/bench_kernel_stats.csv && head -12 $OUT/bench_kernel_stats.csv | cut -c1-200;;
 probe)
   timeout 600 python tools/gpu_probe.py > $OUT/probe.log 2>&1; cp gpurun_out/probe.json $OUT/ 2>/dev/null; tail -3 $OUT/probe.log;;
