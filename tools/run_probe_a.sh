@@ -1,6 +1,4 @@
-O=gpurun_out/r03p8; mkdir -p $O
-NVL_BENCH_LIB=$(pwd)/tmp_ab/libnvl_hip_old.so timeout 300 python tools/norm_bench.py > $O/norm_old.json 2> $O/norm_old.err; echo "old rc=$?"; cat $O/norm_old.json
-timeout 300 python tools/norm_bench.py > $O/norm_new.json 2> $O/norm_new.err; echo "new rc=$?"; cat $O/norm_new.json
-timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "norm or splitk or rms or silu" > $O/pytest_norm.log 2>&1; echo "norm tests rc=$?"; tail -1 $O/pytest_norm.log
-timeout 900 python -m pytest tests/test_e2e_gpu.py -m gpu -q -x > $O/pytest_e2e.log 2>&1; echo "e2e rc=$?"; tail -1 $O/pytest_e2e.log
-timeout 900 python -m pytest tests/test_tp_gpu.py -m gpu -q -x -k "p2p_collectives_between_processes or tp2" > $O/pytest_tp.log 2>&1; echo "tp rc=$?"; tail -1 $O/pytest_tp.log
+O=gpurun_out/r03p9; mkdir -p $O
+for a in 2 0 2 0; do NVL_DECODE_AHEAD=$a NVL_BENCH_MS=16,64,131,144,208,256 timeout 400 python tools/gemm_bench.py 0.6b > $O/gemm_ahead$a.json 2> $O/gemm_ahead$a.err; echo "ahead=$a rc=$?"; python -c "
+import json;d=json.load(open('$O/gemm_ahead$a.json'));print({k:v[0] for k,v in d['time_us'].items()}, d['relerr_max'])"; done
+timeout 600 python -m pytest tests/test_kernels_gpu.py -m gpu -q -x -k "linear_decode or splitk or packed" > $O/pytest_gemm.log 2>&1; echo "gemm tests rc=$?"; tail -1 $O/pytest_gemm.log
