@@ -7,8 +7,15 @@ import json
 import sys
 
 # the launches tools/prefill_bench.py makes, in order: one correctness call, then 13 calls (3 warm + 10 timed) per case
+import random
+random.seed(0)                      # the same ragged batches tools/prefill_bench.py draws
+_ragged = []
+while sum(_ragged) + 1024 <= 16384:
+    _ragged.append(random.randint(100, 1024))
+_short = [random.randint(100, 180) for _ in range(110)]
 CASES = [("spot check 300+129+64, 8/2 heads", 493, 8, 2, 1), ("0.6B 16x1024", 16384, 16, 8, 13),
-         ("bench-like 29x561", 29 * 561, 16, 8, 13), ("0.6B 4x4096", 16384, 16, 8, 13),
+         ("bench-like 29x561", 29 * 561, 16, 8, 13), (f"bench ragged U[100,1024] x{len(_ragged)}", sum(_ragged), 16, 8, 13),
+         ("110 short U[100,180]", sum(_short), 16, 8, 13), ("0.6B 4x4096", 16384, 16, 8, 13),
          ("32B/TP8 1x16384 (config 5)", 16384, 8, 1, 13), ("0.6B 1x16384", 16384, 16, 8, 13),
          ("32B 8x2048 G=8", 16384, 64, 8, 13)]
 rows = []
