@@ -10,6 +10,9 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-readelf"),
+                                reason="needs the ROCm LLVM binutils (llvm-readelf / llvm-objdump)")
+
 
 @pytest.fixture(scope="module")
 def kernels():
