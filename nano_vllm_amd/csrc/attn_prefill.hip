@@ -495,7 +495,7 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   const size_t lds = (size_t)2 * kTileBytes + 8 * sizeof(int) + (size_t)(num_seqs + 1) * sizeof(int);
   const float sl2 = softmax_scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
-  // NVL_PREFILL_XCD=1: XCD-aware workgroup numbering (see the kernel). Off by default — measured A/B on MI355X
+  // XCD-aware workgroup numbering (see the kernel). Round 2's kernel, measured A/B on MI355X
   // (profiles/r02_prefill_xcd{0,1}.json): 4 x 4096 +1.5 %, 8 x 2048 / G = 8 +1.5 %, 16 x 1024 +0.7 %, bench-like
   // 29 x 561 -3 %, 1 x 16384 (16 / 8 heads) -12 %: co-locating a group's heads helps less than it hurts the
   // longest-first balance across XCDs.
@@ -504,15 +504,21 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // 908 / 931 (16/8 heads), 819 / 856 (8/1); 4 x 4096 693 / 718; 8 x 2048 G = 8 741 / 743; but 16 x 1024 497 / 422
   // and 29 x 561 343 / 326: short sequences have too few tiles per workgroup to amortise the 8-wave barrier.
   // NVL_PREFILL_WAVES=4|8 forces one shape; 8 needs an even group size Hq / Hkv.
-  static int xcd_map = -1, waves = -1;
-  if (xcd_map < 0) {
+  // Round 3, with the current kernel (profiles/r03_prefill_ab_xcd_*.json, 4-wave shape, two A/B pairs): the XCD-aware
+  // numbering is +3...11 % on bench-like / ragged batches of 100-1024-token prompts, +-1 % on the long shapes, -2...4 %
+  // on launches of > 64 very short sequences => ON by default for 4-wave launches of <= 64 sequences; NVL_PREFILL_XCD=0|1
+  // forces it off / on for every launch.
+  static int xcd_env = -2, waves = -1;
+  if (xcd_env == -2) {
     const char* e = getenv("NVL_PREFILL_XCD");
-    xcd_map = (e && e[0] == '1') ? 1 : 0;
+    xcd_env = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
     const char* w = getenv("NVL_PREFILL_WAVES");
     waves = (w && w[0] == '8') ? 8 : ((w && w[0] == '4') ? 4 : 0);
   }
   const int want = waves ? waves : (max_seqlen_q >= 2048 ? 8 : 4);
-  const bool eight = want == 8 && !xcd_map && (num_q_heads / num_kv_heads) % 2 == 0;
+  const bool eight_ok = (num_q_heads / num_kv_heads) % 2 == 0;
+  const int xcd_map = xcd_env >= 0 ? xcd_env : ((want == 4 || !eight_ok) && num_seqs <= 64 ? 1 : 0);
+  const bool eight = want == 8 && !xcd_map && eight_ok;
   dim3 grid((unsigned)(eight ? num_q_heads / 2 : num_q_heads), (unsigned)tiles);
   if (xcd_map) {
     const int64_t groups = tiles * num_kv_heads;
