@@ -23,7 +23,7 @@ def xcd_grid(tiles_bound, hq, hkv):
     return out
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (64, 8), (8, 1), (8, 2), (4, 2), (8, 8)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (64, 8), (8, 1), (8, 2), (4, 2), (8, 8), (2, 1), (4, 1), (2, 2), (1, 1), (40, 8)])
 @pytest.mark.parametrize("tiles", [1, 2, 7, 8, 9, 33, 130])
 def test_xcd_numbering_covers_every_head_and_tile_once(hq, hkv, tiles):
     m = xcd_grid(tiles, hq, hkv)
