@@ -52,36 +52,60 @@ def is_fresh() -> bool:
         return fh.read().strip() == _digest()
 
 
+def _source_digest(src: str) -> str:
+    """One translation unit: the source, every header it could include, the flags."""
+    h = hashlib.sha256()
+    for f in [src] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]:
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile every csrc/*.hip for gfx950 into one shared library; returns its path."""
+    """Compile every csrc/*.hip for gfx950 into one shared library; returns its path. Objects are cached per source
+    under lib/obj/ (git- and gpurun-ignored), so editing one kernel file recompiles that file only."""
     os.makedirs(LIBDIR, exist_ok=True)
     if not force and is_fresh():
         return LIB
     hipcc = _hipcc()
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
     for src in sources():
-        obj = os.path.join(LIBDIR, os.path.basename(src)[:-4] + ".o")
+        base = os.path.basename(src)[:-4]
+        obj = os.path.join(objdir, base + ".o")
+        stamp = os.path.join(objdir, base + ".stamp")
+        objs.append(obj)
+        digest = _source_digest(src)
+        if not force and not verbose and os.path.exists(obj) and os.path.exists(stamp):
+            with open(stamp) as fh:
+                if fh.read().strip() == digest:
+                    continue
         cmd = [hipcc, f"--offload-arch={ARCH}", *FLAGS, "-c", src, "-o", obj]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
             print(" ".join(cmd), flush=True)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-        objs.append(obj)
+        procs.append((src, stamp, digest,
+                      subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
-    for src, p in procs:
+    for src, stamp, digest, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             failed = True
             sys.stderr.write(f"--- hipcc failed on {src}\n{out}\n")
-        elif verbose or out.strip():
-            sys.stderr.write(out)
+            if os.path.exists(stamp):
+                os.remove(stamp)
+        else:
+            with open(stamp, "w") as fh:
+                fh.write(digest)
+            if verbose or out.strip():
+                sys.stderr.write(out)
     if failed:
         raise RuntimeError("hipcc compilation failed")
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", *objs, "-o", LIB]
     subprocess.run(cmd, check=True)
-    for o in objs:
-        os.remove(o)
     with open(STAMP, "w") as fh:
         fh.write(_digest())
     return LIB

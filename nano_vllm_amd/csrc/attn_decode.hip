@@ -36,6 +36,7 @@
 // from HBM inside this launch, so there is no intra-launch dependency to order.
 #include "common.h"
 #include <stdlib.h>
+#include <mutex>
 #include "rope_common.h"
 
 namespace {
@@ -656,9 +657,13 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   if (plan != nullptr) {
     // per-step plan: header + this wave's record, two scalar loads (the addresses are wave-uniform); no LDS prefix,
     // no barrier, no search
-    total = plan->total;
+    // A plan is only valid for the (batch, Hkv, grid) it was built for. The host side refuses a mismatch
+    // (plan_shadow_check); should one reach the device anyway — a replayed graph whose plan buffer was overwritten by a
+    // differently shaped nvl_decode_plan — the launch does NO work instead of indexing past the records.
+    const bool plan_ok = plan->nwaves == (int)(gridDim.x * kWaves) && plan->batch == batch && plan->hkv == hkv;
+    total = plan_ok ? plan->total : 0;
     per = plan->per;
-    first_seg = reinterpret_cast<const PlanEntry*>(plan + 1)[wid];
+    if (plan_ok) first_seg = reinterpret_cast<const PlanEntry*>(plan + 1)[wid];
   } else {
     chunk_prefix(ctx, batch, kTile, pre, wsum);
     __syncthreads();
@@ -1157,6 +1162,40 @@ bool use_valu_g8() {
   return v == 1;
 }
 
+// Host-side shadow of the plans nvl_decode_plan has enqueued (keyed by the plan buffer's address): the attention entry
+// points compare the geometry a plan was built for with the launch they are about to make — a plan is a list of
+// per-wave records for ONE (batch, Hkv, max_context, device) and the kernel indexes it by wave id.
+struct PlanShadow { const void* plan; int64_t batch, max_context; int hkv, dev; };
+static PlanShadow g_plan_shadow[64];
+static int g_plan_shadow_n = 0, g_plan_shadow_next = 0;
+static std::mutex g_plan_shadow_mu;
+
+static void plan_shadow_put(const void* plan, int64_t batch, int hkv, int64_t max_context) {
+  std::lock_guard<std::mutex> lock(g_plan_shadow_mu);
+  const PlanShadow rec = {plan, batch, max_context, hkv, nvl_device_slot()};
+  for (int i = 0; i < g_plan_shadow_n; ++i)
+    if (g_plan_shadow[i].plan == plan && g_plan_shadow[i].dev == rec.dev) { g_plan_shadow[i] = rec; return; }
+  if (g_plan_shadow_n < 64) { g_plan_shadow[g_plan_shadow_n++] = rec; return; }
+  g_plan_shadow[g_plan_shadow_next] = rec;                 // more than 64 live plan buffers: forget the oldest
+  g_plan_shadow_next = (g_plan_shadow_next + 1) % 64;
+}
+
+static int plan_shadow_check(const void* plan, int64_t batch, int hkv, int64_t max_context, const char* who) {
+  std::lock_guard<std::mutex> lock(g_plan_shadow_mu);
+  const int dev = nvl_device_slot();
+  for (int i = 0; i < g_plan_shadow_n; ++i)
+    if (g_plan_shadow[i].plan == plan && g_plan_shadow[i].dev == dev) {
+      const PlanShadow& r = g_plan_shadow[i];
+      NVL_REQUIRE(r.batch == batch && r.hkv == hkv && r.max_context == max_context,
+                  "%s: the plan was built for batch=%lld, Hkv=%d, max_context=%lld; this launch has batch=%lld, Hkv=%d, "
+                  "max_context=%lld (a plan serves exactly the step it was made for)", who, (long long)r.batch, r.hkv,
+                  (long long)r.max_context, (long long)batch, hkv, (long long)max_context);
+      return NVL_OK;
+    }
+  NVL_REQUIRE(false, "%s: plan %p was not produced by nvl_decode_plan on this device", who, plan);
+  return NVL_OK;
+}
+
 int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* block_tables, int64_t bt_stride,
                   const int32_t* context_lens, void* out, int64_t batch, int num_q_heads, int num_kv_heads,
                   int block_size, int64_t num_blocks, int64_t max_context, float softmax_scale, void* workspace,
@@ -1173,6 +1212,10 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
               "%s: pointers must be 16-byte aligned", who);
   NVL_REQUIRE(((uintptr_t)plan % 16 == 0) && ((uintptr_t)lse % 4 == 0), "%s: plan must be 16-byte, lse 4-byte aligned", who);
   if (batch == 0) return NVL_OK;
+  if (plan != nullptr) {
+    const int rc = plan_shadow_check(plan, batch, num_kv_heads, max_context, who);
+    if (rc != NVL_OK) return rc;
+  }
   const int G = num_q_heads / num_kv_heads;
   const size_t need = nvl_paged_attn_decode_workspace_bytes(batch, num_q_heads, max_context);
   NVL_REQUIRE(workspace_bytes >= need, "%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
@@ -1330,5 +1373,6 @@ extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int n
   }
   hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, context_lens, (int)batch,
                      num_kv_heads, nwaves, (PlanHeader*)plan);
+  plan_shadow_put(plan, batch, num_kv_heads, max_context);
   return nvl_check_launch(who);
 }

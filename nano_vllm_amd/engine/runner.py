@@ -271,9 +271,7 @@ class ModelRunner:
                 load_model(self.model, config.model)
             # tile-packed copies of the deep-K projections for the decode GEMM (before the KV pool is sized from what
             # is left: a second copy of those weights is the price of a 4x cheaper weight stream per CU)
-            from ..layers import LinearBase, ParallelLMHead
-            self.packed_weight_bytes = sum(m.pack_for_decode() for m in self.model.modules()
-                                           if isinstance(m, (LinearBase, ParallelLMHead)))
+            self.packed_weight_bytes, self.packed_weight_skipped = self._pack_weights()
             self.sampler = Sampler(seed=config.seed, max_rows=config.max_num_seqs)
             # decode micro-batching (see _forward_decode): second chain's stream, sampler and workspace
             self.microbatches = int(os.environ.get("NVL_MICROBATCHES", "1")) if self.world_size == 1 else 1
@@ -300,6 +298,26 @@ class ModelRunner:
                 dist.barrier()
                 self.chan = _Channel(name, payload, self.world_size, create=False)
                 self.loop()
+
+    def _pack_weights(self) -> tuple[int, int]:
+        """Tile-packed second copies of the decode GEMMs' weights, under a BUDGET: they are allocated before the KV
+        pool is sized, so every packed byte is a KV-cache byte less (Qwen3-32B at TP = 1: 64 GB of copies). Budget =
+        min(NVL_PACKED_BUDGET_FRAC (default 0.25) x device memory, half of what is free once the weights are loaded);
+        projections are packed in model order until the next one no longer fits, the rest keep the row-major weight
+        stream (slower decode GEMM, same results bit for bit) — on a 192 GB part Qwen3-32B packs its first ~48 GB and
+        keeps its KV pool. Returns (bytes packed, projections left unpacked for lack of budget)."""
+        from ..layers import LinearBase, ParallelLMHead
+        free, total = torch.cuda.mem_get_info(self.device)
+        budget = min(float(os.environ.get("NVL_PACKED_BUDGET_FRAC", "0.25")) * total, 0.5 * free)
+        used = skipped = 0
+        for m in self.model.modules():
+            if isinstance(m, (LinearBase, ParallelLMHead)):
+                got = m.pack_for_decode(budget - used)
+                if got < 0:
+                    skipped += 1
+                else:
+                    used += got
+        return used, skipped
 
     # ------------------------------------------------------------------ lifecycle / TP control channel
     def exit(self):

@@ -295,11 +295,12 @@ class LinearBase(nn.Module):
             self.register_parameter("bias", None)
         self.weight_packed: torch.Tensor | None = None     # tile-packed copy for nvl_linear_wide (pack_for_decode)
 
-    def pack_for_decode(self) -> int:
+    def pack_for_decode(self, budget_bytes: float = float("inf")) -> int:
         """After the weights are loaded: keep a tile-packed copy (ops.pack_weight_tiles) of a projection whose decode
         GEMM is one of the hand-written kernels — the skinny kernel (K <= 1024-3072: Qwen3-0.6B) or the wide-tile one
         (deep reductions: Qwen3-8B / 32B shapes). The row-major parameter stays: prefill-sized GEMMs run on hipBLASLt
-        from it. Returns the extra bytes. NVL_PACKED_WEIGHTS=0 keeps the row-major weight stream (A/B measurements)."""
+        from it. Returns the extra bytes (0: shape not covered; -1: covered, but the copy does not fit `budget_bytes`
+        — ModelRunner._pack_weights). NVL_PACKED_WEIGHTS=0 keeps the row-major weight stream (A/B measurements)."""
         n, k = self.weight.shape
         if (self.bias is not None or not self.weight.is_cuda or n % 16 or k % 32
                 or os.environ.get("NVL_PACKED_WEIGHTS", "1") == "0"):
@@ -309,6 +310,8 @@ class LinearBase(nn.Module):
                 and ops.linear_wide_plan(144, n, k, ops.LINEAR_BF16) is not None)
         if not (skinny or wide):
             return 0
+        if n * k * 2 > budget_bytes:
+            return -1
         self.weight_packed = ops.pack_weight_tiles(self.weight.data)
         return self.weight_packed.numel() * 2
 
@@ -591,7 +594,7 @@ class ParallelLMHead(VocabParallelEmbedding):
         super().__init__(num_embeddings, embedding_dim)
         self.weight_packed: torch.Tensor | None = None
 
-    def pack_for_decode(self) -> int:
+    def pack_for_decode(self, budget_bytes: float = float("inf")) -> int:
         """Tile-packed copy of the vocabulary matrix for the decode step's lm_head GEMM on deep hidden sizes
         (Qwen3-8B / 32B: K >= 2048, where nvl_linear_wide on packed weights beats the library GEMM at <= 144 rows —
         profiles/r03_gemm_wide_lm_head.json; at K = 1024, Qwen3-0.6B, the library GEMM stays). Returns the extra bytes."""
@@ -600,6 +603,8 @@ class ParallelLMHead(VocabParallelEmbedding):
                 or os.environ.get("NVL_GEMM_WIDE", "auto") == "0" or os.environ.get("NVL_PACKED_LM_HEAD", "1") == "0"
                 or ops.linear_wide_plan(144, n, k, ops.LINEAR_BF16) is None):
             return 0
+        if n * k * 2 > budget_bytes:
+            return -1
         self.weight_packed = ops.pack_weight_tiles(self.weight.data)
         return self.weight_packed.numel() * 2
 

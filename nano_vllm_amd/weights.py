@@ -37,6 +37,10 @@ QWEN3_SHAPES = {
     # two full-width layers of the large models (tests: the layer code paths real 8B / 32B widths take)
     "qwen3-8b-2l": (4096, 12288, 2, 32, 8, False),
     "qwen3-32b-2l": (5120, 25600, 2, 64, 8, False),
+    # what ONE rank of Qwen3-32B at tensor_parallel_size = 8 holds (models/qwen3.py:29-38, layers/linear.py:54-156: 8 query
+    # heads, 1 kv head, intermediate 25600 / 8; with vocab_size 151936 / 8 also its embedding / lm_head shard): run as a
+    # TP = 1 engine it does a rank's work minus the collectives — bench.py's `tp8_rank_shape` upper bound
+    "qwen3-32b-tp8rank": (5120, 3200, 64, 8, 1, False),
 }
 
 

@@ -46,6 +46,7 @@ class OracleEngine:
         self.gen = torch.Generator().manual_seed(seed)
         self.trace: list[dict] = []          # per-step record for tests (schedule + tables + logits)
         self.keep_logits = False
+        self.choose = None                   # tests: callable(step record, logits) -> tokens, replaces the sampler
         if model is not None:
             model.allocate_cache(num_blocks, block_size)
 
@@ -239,6 +240,8 @@ class OracleEngine:
                 tokens = torch.where(temps > 0, sampled, greedy).tolist()
             else:
                 tokens = greedy.tolist()
+            if self.choose is not None:
+                tokens = self.choose(rec, logits.float())
             if self.keep_logits:
                 rec["logits"] = logits.float()
             top2 = logits.float().topk(2, dim=-1).values

@@ -19,7 +19,8 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run_ours(path, prompts, max_tokens, capture_logits=False, **kw):
+def _run_ours(path, prompts, max_tokens, capture_logits=False, temperatures=None, **kw):
+    """`temperatures` (per prompt; None = greedy). The engine's draw seed is `kw["seed"]` (Config.seed, default 0)."""
     from nano_vllm_amd import LLM, SamplingParams
     llm = LLM(path, **kw)
     rec = []
@@ -51,7 +52,8 @@ def _run_ours(path, prompts, max_tokens, capture_logits=False, **kw):
         return out
 
     runner.call = spy
-    sps = [SamplingParams(temperature=0.0, max_tokens=m, ignore_eos=True) for m in max_tokens]
+    temperatures = temperatures if temperatures is not None else [0.0] * len(prompts)
+    sps = [SamplingParams(temperature=t, max_tokens=m, ignore_eos=True) for t, m in zip(temperatures, max_tokens)]
     outs = llm.generate(prompts, sps, use_tqdm=False)
     nblk = llm.config.num_kvcache_blocks
     runner.call = orig
@@ -63,9 +65,10 @@ def _run_ours(path, prompts, max_tokens, capture_logits=False, **kw):
     return outs, rec, nblk
 
 
-def _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device=None, **sched_kw):
+def _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device=None, temperatures=None, seed=0, **sched_kw):
     from oracle.judge import judge_run
-    return judge_run(cfg, w, prompts, max_tokens, rec, nblk, device=device, **sched_kw)
+    return judge_run(cfg, w, prompts, max_tokens, rec, nblk, device=device, temperatures=temperatures, seed=seed,
+                     **sched_kw)
 
 
 def _check(name, v, min_rows=1):
@@ -74,10 +77,10 @@ def _check(name, v, min_rows=1):
     assert v.ok(), v.violations[:5]
 
 
-def _judge(path, prompts, max_tokens, rec, nblk, **sched_kw):
+def _judge(path, prompts, max_tokens, rec, nblk, temperatures=None, seed=0, **sched_kw):
     from oracle.model import load_weights
     cfg, w = load_weights(path)
-    return _judge_run(cfg, w, prompts, max_tokens, rec, nblk, **sched_kw)
+    return _judge_run(cfg, w, prompts, max_tokens, rec, nblk, temperatures=temperatures, seed=seed, **sched_kw)
 
 
 @pytest.fixture(scope="module")
@@ -134,6 +137,46 @@ def test_tiny_model_chunked_prefill_and_preemption(tiny_ckpt):
                                           max_num_batched_tokens=640), sum(max_tokens))
 
 
+# ---------------------------------------------------------------------------------------------
+# T > 0 — the path the headline bench runs (reference layers/sampler.py:8-12 behind model_runner.py:214-220, bench.py:18
+# T = 0.6), judged EXACTLY: the product's draw is a counter-based function of (seed, request ordinal, position, column)
+# which oracle/philox.py restates, so every sampled token must be the argmax of `l/T - log E` on the oracle's logits
+# whenever the key margin exceeds 2 x floor / T (oracle/judge.py). What this pins end to end: the per-row key staging
+# (`rkey` = ordinal | position << 32 in prefill AND decode images, through the lookahead's pre-staged steps), the
+# graph-captured sampler reading keys/temperatures from the static device block, mid-prefill chunk rows, and mixed
+# greedy / sampled batches.
+@pytest.mark.parametrize("eager", [True, False])
+def test_tiny_model_sampled_parity_draws_replayed(tiny_ckpt, eager):
+    prompts = _prompts(7, 5, 600, 512, seed=3)
+    max_tokens = [24, 40, 8, 33, 1, 17, 29]
+    temps = [0.6, 1.0, 0.0, 0.6, 0.8, 1.5, 0.3]
+    outs, rec, nblk = _run_ours(tiny_ckpt, prompts, max_tokens, temperatures=temps, enforce_eager=eager,
+                                max_model_len=2048, num_kvcache_blocks=32, max_num_seqs=16, seed=1234)
+    assert [len(o["token_ids"]) for o in outs] == max_tokens
+    v = _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, temperatures=temps, seed=1234, max_num_seqs=16)
+    _check(f"tiny T>0 eager={eager}", v, sum(max_tokens))
+    assert v.sampled_rows >= sum(max_tokens) - 8
+    # the judgement has teeth: the same run under another seed is refused
+    assert not _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, temperatures=temps, seed=1235, max_num_seqs=16).ok()
+
+
+def test_tiny_model_sampled_parity_through_chunked_prefill_and_preemption(tiny_ckpt):
+    """T = 0.6 with chunked prefill (a mid-prefill chunk's discarded token is still drawn with the key of ITS end
+    position), prefix-cache hits and a preemption by recompute: a re-prefilled sequence must draw, at each position, the
+    numbers it would have drawn without the preemption (the key is (request, position), not a step counter)."""
+    g = torch.Generator().manual_seed(11)
+    shared = torch.randint(0, 512, (512,), generator=g).tolist()
+    prompts = [shared + torch.randint(0, 512, (int(n),), generator=g).tolist() for n in (30, 200, 77, 5)]
+    prompts.append(torch.randint(0, 512, (900,), generator=g).tolist())
+    max_tokens, temps = [20] * 5, [0.6] * 5
+    outs, rec, nblk = _run_ours(tiny_ckpt, prompts, max_tokens, temperatures=temps, enforce_eager=False,
+                                max_model_len=2048, num_kvcache_blocks=9, max_num_seqs=8, max_num_batched_tokens=640,
+                                seed=7)
+    assert any(r["prefill"] and len(r["seq_ids"]) == 1 for r in rec)
+    _check("tiny T=0.6 chunked/preempt", _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, temperatures=temps, seed=7,
+                                                max_num_seqs=8, max_num_batched_tokens=640), sum(max_tokens))
+
+
 def test_sampling_temperature_runs_and_is_seeded(tiny_ckpt):
     from nano_vllm_amd import LLM, SamplingParams
     prompts = _prompts(4, 5, 100, 512, seed=5)
@@ -176,6 +219,29 @@ def test_lookahead_equals_serial_when_sampled_eos_ends_sequences(tiny_ckpt, monk
     diff_tok = sum(sum(x != y for x, y in zip(a, b)) + abs(len(a) - len(b)) for a, b in zip(look, serial))
     print(f"{ended}/48 sequences ended on a sampled EOS; {same_seq}/48 sequences identical, {diff_tok}/{n_tok} tokens differ")
     assert ended >= 1 and same_seq >= 44 and diff_tok <= 0.01 * n_tok
+
+
+def test_packed_weight_copies_obey_their_budget_and_do_not_change_results(tiny_ckpt, monkeypatch):
+    """The tile-packed second copies of the decode GEMMs' weights are allocated before the KV pool is sized; under a
+    budget that does not fit them (NVL_PACKED_BUDGET_FRAC ~ 0) the projections keep the row-major weight stream — same
+    arithmetic in the same order, so the tokens are identical — and the runner reports what it left unpacked."""
+    from nano_vllm_amd import LLM, SamplingParams
+    prompts = _prompts(5, 5, 300, 512, seed=61)
+    sp = SamplingParams(temperature=0.0, max_tokens=10, ignore_eos=True)
+
+    def run(frac):
+        monkeypatch.setenv("NVL_PACKED_BUDGET_FRAC", frac)
+        llm = LLM(tiny_ckpt, enforce_eager=False, max_model_len=1024, num_kvcache_blocks=16, max_num_seqs=8)
+        r = llm.model_runner
+        stats = (r.packed_weight_bytes, r.packed_weight_skipped)
+        toks = [o["token_ids"] for o in llm.generate(prompts, sp, use_tqdm=False)]
+        llm.exit()
+        return stats, toks
+
+    (full_bytes, full_skipped), a = run("0.25")
+    (none_bytes, none_skipped), b = run("1e-12")
+    assert full_bytes > 0 and full_skipped == 0 and none_bytes == 0 and none_skipped > 0
+    assert a == b
 
 
 def test_string_prompts_and_eos(tiny_ckpt):
@@ -267,6 +333,41 @@ def test_config2_shaped_batch_greedy_parity_vs_device_oracle(ckpt_06b):
     cfg, w = _oracle_weights_06b("cuda")
     v = _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device="cuda", max_num_seqs=64)
     _check("config-2-shaped batch (64 seqs x 33 tokens, 0.6B width)", v, 64 * 33)
+
+
+def test_config2_shaped_batch_sampled_T06_parity_vs_device_oracle(ckpt_06b):
+    """The headline configuration's OWN path judged end to end: the bench's ragged prompts (seeded like the reference
+    bench.py), temperature 0.6, `ignore_eos`, 64 sequences x 33 tokens => three prefill batches + 32 hipGraph decode
+    steps at B = 64 with the lookahead on, full 151,936-column vocabulary. Every one of the 2,112 sampled tokens must be
+    the argmax of `l/0.6 - log E` on the device-resident oracle's logits (draws replayed by oracle/philox.py) wherever
+    the key margin exceeds 2 x floor / T."""
+    from random import Random
+    rnd = Random(0)
+    prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(100, 1024))] for _ in range(64)]
+    max_tokens, temps = [33] * 64, [0.6] * 64
+    outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, temperatures=temps, enforce_eager=False,
+                                max_model_len=4096, num_kvcache_blocks=400, max_num_seqs=64, dummy_weights=True, seed=0)
+    assert sum(1 for r in rec if not r["prefill"] and len(r["tokens"]) == 64) == 32
+    greedy_like = sum(len(set(o["token_ids"])) for o in outs)
+    assert greedy_like > 64 * 8                            # (sampled text, not a stuck argmax loop)
+    cfg, w = _oracle_weights_06b("cuda")
+    v = _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device="cuda", temperatures=temps, seed=0, max_num_seqs=64)
+    _check("config-2-shaped batch at T = 0.6 (64 seqs x 33 tokens, 0.6B width)", v, 64 * 33)
+    assert v.sampled_rows == 64 * 33
+
+
+def test_qwen3_06b_fused_lm_head_sampled_T06_parity(ckpt_06b, monkeypatch):
+    """The opt-in nvl_lmhead_sample path (the race run inside the lm_head GEMM's epilogue) at T = 0.6 under the same
+    exact rule: its epilogue must draw the same (request, position, column)-keyed numbers as the standalone sampler."""
+    import nano_vllm_amd.layers as layers_mod
+    monkeypatch.setattr(layers_mod, "_FUSED_LMHEAD", True)
+    prompts = _prompts(3, 20, 300, 10000, seed=21)
+    max_tokens, temps = [8, 6, 7], [0.6, 0.6, 1.0]
+    outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, temperatures=temps, enforce_eager=False,
+                                max_model_len=1024, num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True, seed=3)
+    cfg, w = _oracle_weights_06b("cuda")
+    _check("0.6B shapes, fused lm_head, T > 0", _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device="cuda",
+                                                            temperatures=temps, seed=3, max_num_seqs=8), sum(max_tokens))
 
 
 def test_config1_example_prompts_eager_exact_tokens(ckpt_06b):

@@ -423,7 +423,6 @@ def test_p2p_comm_construction_always_joins_its_collectives(mode, monkeypatch):
     from nano_vllm_amd import ops
     fake = _FakeCommLib(fail_create=mode == "create_fails", fail_connect=mode == "connect_fails")
     monkeypatch.setattr(ops, "lib", lambda: fake)
-    monkeypatch.delenv("NVL_TP_P2P_FENCES", raising=False)
     joined = []
 
     def exchange(blob):

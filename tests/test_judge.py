@@ -87,3 +87,85 @@ def test_reference_eager_run_passes_the_gate_of_the_compiled_reference(tiny):
     bad[i]["tokens"][row] = wrong
     v = judge_run(cfg, w, prompts, max_tokens, bad, 16, max_num_seqs=8)
     assert not v.ok() and v.violations[0]["step"] == i and v.violations[0]["row"] == row
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# T > 0: the draw restated in oracle/philox.py, and the race-key form of the rule
+def test_philox_known_answers_and_the_product_library_replay_agree():
+    """oracle/philox.py against (a) the Random123 known-answer vectors of Philox4x32-10 and (b) the product library's
+    host replay of its own draw (nvl_sample_exponentials_host: host code of libnvl_hip.so, no GPU needed) — two
+    independent implementations of the keying written down in oracle/philox.py's header."""
+    import numpy as np
+    from nano_vllm_amd import ops
+    from oracle.philox import exponentials, philox4x32_10
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        assert tuple(int(x) for x in philox4x32_10(*ctr, *key)) == want
+    for seed, ordinal, position, col0, n in [(1234, 5, 77, 0, 4099), ((7 << 32) | 99, 0xfffffff0, (3 << 24) | 12345,
+                                                                     151936 - 64, 64), (0, 0, 0, 8, 151936 // 8)]:
+        theirs = ops.sample_exponentials_host(seed, position, ordinal, col0, n)
+        mine = exponentials(seed, ordinal, position, n, col0)
+        assert np.abs(theirs - mine).max() <= 2e-6 * max(1.0, float(theirs.max()))     # libm vs numpy log: last bit
+        assert theirs.min() >= 1e-10 and mine.min() >= 1e-10
+
+
+def test_race_key_rule_on_synthetic_rows():
+    import numpy as np
+    from oracle.philox import race_keys
+    g = torch.Generator().manual_seed(3)
+    lg = torch.randn(3, 4096, generator=g) * 3
+    draws = [(0.6, 11, r, 40 + r) for r in range(3)]
+    keys = [race_keys(lg[r].numpy(), *draws[r]) for r in range(3)]
+    best = [int(np.argmax(k)) for k in keys]
+    assert best != [int(x) for x in lg.argmax(-1)]                 # the draw matters: not the greedy tokens
+    j = Judge()
+    j.add_step(lg, best, lg + 1e-3, draws=draws)
+    v = j.verdict()
+    assert v.ok() and v.exact == 3 and v.sampled_rows == 3
+    # the greedy token instead of the sampled one on a row whose key margin is decisive: caught
+    j = Judge()
+    j.add_step(lg, [int(lg[0].argmax())] + best[1:], lg + 1e-3, draws=draws)
+    assert not j.verdict().ok()
+    # a different position (= another draw) moves the winner: the key really is (ordinal, position)
+    assert int(np.argmax(race_keys(lg[0].numpy(), 0.6, 11, 0, 41))) != best[0]
+    # mixed batch: a T = 0 row next to sampled rows is judged on the logits
+    j = Judge()
+    j.add_step(lg, [int(lg[0].argmax())] + best[1:], lg + 1e-3, draws=[None] + draws[1:])
+    v = j.verdict()
+    assert v.ok() and v.sampled_rows == 2
+
+
+def test_sampled_run_of_the_oracle_is_judged_exact_and_a_wrong_draw_is_caught(tiny):
+    """A free run that samples with the replayed draws (temperature 0.6 and 1.3 next to a greedy request, chunk-free
+    prefill + decode) passes `judge_run(..., temperatures=, seed=)` with every token exact; the same tokens judged under
+    another seed fail."""
+    import numpy as np
+    from oracle.engine import OracleEngine
+    from oracle.model import OracleQwen3
+    from oracle.philox import race_keys
+    cfg, w = tiny
+    g = torch.Generator().manual_seed(8)
+    prompts = [torch.randint(0, 512, (n,), generator=g).tolist() for n in (33, 260, 9)]
+    max_tokens, temps, seed = [9, 7, 11], [0.6, 0.0, 1.3], 42
+    eng = OracleEngine(OracleQwen3(cfg, w, compiled=True), 16, 256, max_num_seqs=8)
+    for p, m in zip(prompts, max_tokens):
+        eng.add(p, 0.0, m, True)
+
+    def choose(t, logits):                    # sample with the replayed draw: request ordinal = id, position = cached + sched
+        return [int(np.argmax(race_keys(logits[row].numpy(), temps[sid], seed, sid, c + n))) if temps[sid] > 0
+                else int(logits[row].argmax()) for row, (sid, c, n) in enumerate(zip(t["seq_ids"], t["cached"], t["sched"]))]
+
+    eng.choose = choose
+    rec = []
+    while eng.waiting or eng.running:
+        eng.step()
+        t = eng.trace[-1]
+        rec.append(dict(prefill=t["is_prefill"], seq_ids=list(t["seq_ids"]), tables=[list(x) for x in t["tables"]],
+                        tokens=list(t["tokens"])))
+    v = judge_run(cfg, w, prompts, max_tokens, rec, 16, temperatures=temps, seed=seed, max_num_seqs=8)
+    print(v.line("oracle sampled run judged by itself"))
+    assert v.ok() and v.exact == v.rows == sum(max_tokens) and v.sampled_rows == 9 + 11
+    assert not judge_run(cfg, w, prompts, max_tokens, rec, 16, temperatures=temps, seed=seed + 1, max_num_seqs=8).ok()

@@ -827,6 +827,133 @@ def test_fp8_kv_prefill_paged_prefix(ops, hq, hkv):
 
 
 # ------------------------------------------------------------------------------------------
+# The pool re-sized for 288 GB: element offsets beyond 2^31 (SURVEY.md §0-12 — the reference's Triton store computes
+# `slot * D` in int32, attention.py:22-30, and overflows at this size). A one-layer pool of 8,448 blocks x 8 kv heads
+# (4.4 GB each for K and V in bf16): block 8,192 starts at element 2^31; every kernel that addresses the cache is run
+# on sequences living at block ids >= 8,192 (plus one below, so both sides of the boundary are in one launch) against
+# the oracle, whose small caches hold the same blocks under small ids.
+@pytest.mark.parametrize("kv", ["bf16", "fp8"])
+def test_kv_pool_beyond_2_pow_31_elements(ops, kv):
+    bs, hkv, hq, nblk, max_ctx = 256, 8, 16, 8448, 2048
+    fp8 = kv == "fp8"
+    gen = g(150)
+    free, _ = torch.cuda.mem_get_info()
+    need = 2 * nblk * hkv * bs * 128 * (1 if fp8 else 2)
+    if free < need + (6 << 30):
+        pytest.skip(f"needs {need / 2**30:.1f} GiB of free device memory")
+    dt_dev = torch.float8_e4m3fn if fp8 else BF16
+    kc = torch.zeros(nblk, hkv, bs, 128, dtype=torch.uint8 if fp8 else BF16, device="cuda")
+    vc = torch.zeros_like(kc)
+    if fp8:
+        kc, vc = kc.view(dt_dev), vc.view(dt_dev)
+    assert kc.numel() > 2 ** 31 and (nblk - 1) * hkv * bs * 128 > 2 ** 31
+    # sequences: (context length incl. the token this step appends) on blocks picked from the top of the pool
+    lens = [700, 257, 1024, 33, 512, 2048]
+    nb = [(n + bs - 1) // bs for n in lens]
+    big_ids = [8447, 8192, 8193, 8300, 8446, 8200, 8250, 8400, 8199, 8345, 8222, 8333, 8444, 8211, 8191, 8195,
+               8196, 8197, 8198, 8201, 8202, 8203, 8204, 4097, 8205]
+    assert len(set(big_ids)) == len(big_ids) >= sum(nb) and max(big_ids) < nblk
+    small_of = {bid: i for i, bid in enumerate(big_ids)}             # the oracle's ids for the same blocks
+    bt_big = torch.full((len(lens), max_ctx // bs), -1, dtype=torch.int32)
+    c = 0
+    for s_, n in enumerate(nb):
+        for j in range(n):
+            bt_big[s_, j] = big_ids[c]
+            c += 1
+    bt_small = bt_big.clone()
+    for bid, sid in small_of.items():
+        bt_small[bt_big == bid] = sid
+    # fill the used blocks (product layout [Hkv, bs, 128] per block) and mirror them into the oracle's small caches
+    quant = (lambda t: _fp8_roundtrip(t)) if fp8 else (lambda t: t)
+    kc_small = torch.zeros(len(big_ids), bs, hkv, 128, dtype=BF16)
+    vc_small = torch.zeros_like(kc_small)
+    for bid, sid in small_of.items():
+        kb = quant(torch.randn(hkv, bs, 128, generator=gen).to(BF16))
+        vb = quant(torch.randn(hkv, bs, 128, generator=gen).to(BF16))
+        kc[bid].copy_(kb.to(dt_dev))
+        vc[bid].copy_(vb.to(dt_dev))
+        kc_small[sid] = kb.permute(1, 0, 2)
+        vc_small[sid] = vb.permute(1, 0, 2)
+
+    def rows(cache, bid):                                              # block `bid` of the product pool, token-major bf16
+        return cache[bid].cpu().to(BF16).permute(1, 0, 2) if fp8 else cache[bid].cpu().permute(1, 0, 2)
+
+    # ---- nvl_store_kvcache at slots beyond 2^31 / (Hkv * 128) --------------------------------------------------------
+    n_new = 40
+    k_new = quant(torch.randn(n_new, hkv, 128, generator=gen).to(BF16))
+    v_new = quant(torch.randn(n_new, hkv, 128, generator=gen).to(BF16))
+    spare = [8440, 8441, 5]                                             # blocks no sequence uses
+    slots_big = torch.tensor([spare[i % 3] * bs + (7 * i) % bs for i in range(n_new)], dtype=torch.int32)
+    slots_big[3] = -1
+    ops.store_kvcache(dev(k_new), dev(v_new), kc, vc, dev(slots_big))
+    for i in range(n_new):
+        if i == 3:
+            continue
+        bid, off = int(slots_big[i]) // bs, int(slots_big[i]) % bs
+        assert torch.equal(rows(kc, bid)[off], k_new[i]) and torch.equal(rows(vc, bid)[off], v_new[i])
+    assert not kc[8442].view(torch.uint8).any() and not kc[6].view(torch.uint8).any()    # neighbours untouched
+
+    # ---- fused decode (q/k-norm + RoPE + KV store + attention), plain and planned -------------------------------------
+    b = len(lens)
+    qkv = torch.randn(b, (hq + 2 * hkv) * 128, generator=gen).to(BF16)
+    qw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16)
+    kw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16)
+    table = ref.rope_table(128, max_ctx, 1e6)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    pos = ctx.long() - 1
+    slots_small = torch.tensor([int(bt_small[i, (n - 1) // bs]) * bs + (n - 1) % bs for i, n in enumerate(lens)],
+                               dtype=torch.int32)
+    slots_dec = torch.tensor([int(bt_big[i, (n - 1) // bs]) * bs + (n - 1) % bs for i, n in enumerate(lens)],
+                             dtype=torch.int32)
+    # oracle: the reference's separate steps on the small caches (qwen3.py:83-85, attention.py:63, :72-74)
+    q, k, v = qkv.split([hq * 128, hkv * 128, hkv * 128], dim=-1)
+    qn = ref.rms_forward(q.reshape(b, hq, 128), qw, 1e-6)
+    kn = ref.rms_forward(k.reshape(b, hkv, 128), kw, 1e-6)
+    q_ref, k_ref = ref.rotary_forward(pos, qn, kn, table)
+    ref.store_kvcache(quant(k_ref), quant(v.reshape(b, hkv, 128)), kc_small, vc_small, slots_small)
+    scale = 128 ** -0.5
+    o_ref, lse_ref = ref.flash_attn_with_kvcache(q_ref.unsqueeze(1), kc_small, vc_small, ctx, bt_small, scale,
+                                                 return_softmax_lse=True)
+    o_ref = o_ref.squeeze(1)
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    lse = torch.zeros(b, hq, dtype=torch.float32, device="cuda")
+    o = ops.paged_attn_decode_fused(dev(qkv), dev(qw), dev(kw), 1e-6, dev(table), kc, vc, dev(bt_big), dev(ctx), hq, scale,
+                                    max_ctx, ws, lse=lse)
+    torch.cuda.synchronize()
+    tol = 2e-2 * float(o_ref.float().abs().max()) + (1e-3 if fp8 else 0.0)
+    assert float((o.cpu().float() - o_ref.float()).abs().max()) <= tol
+    assert float((lse.cpu() - lse_ref).abs().max()) <= (6e-3 if fp8 else 2e-3)
+    for i, n in enumerate(lens):                                        # the appended row sits in its high block
+        bid, off = int(slots_dec[i]) // bs, int(slots_dec[i]) % bs
+        got_k, want_k = rows(kc, bid)[off].float(), kc_small[small_of[bid], off].float()
+        assert float((got_k - want_k).abs().max()) <= (0.51 if fp8 else 2 ** -5)          # (1 ulp of norm -> rope)
+        assert torch.equal(rows(vc, bid)[off], vc_small[small_of[bid], off])
+    plan = ops.decode_plan(dev(ctx), hq, hkv, max_ctx)
+    o2 = ops.paged_attn_decode_fused(dev(qkv), dev(qw), dev(kw), 1e-6, dev(table), kc, vc, dev(bt_big), dev(ctx), hq,
+                                     scale, max_ctx, torch.zeros_like(ws), plan=plan)
+    assert torch.equal(o2, o)                                           # (the store is idempotent: same row, same value)
+    # unfused entry point on the same pool
+    q1 = torch.empty(b, hq, 128, dtype=BF16, device="cuda")
+    ops.qknorm_rope_kvstore(dev(qkv), dev(pos), dev(qw), dev(kw), 1e-6, dev(table), dev(slots_dec), q1, None, kc, vc, hq, hkv)
+    o3 = ops.paged_attn_decode(q1, kc, vc, dev(bt_big), dev(ctx), scale, max_ctx, torch.zeros_like(ws))
+    assert float((o3.cpu().float() - o_ref.float()).abs().max()) <= tol
+
+    # ---- paged prefill (prefix cache / chunk continuation) reading the same high blocks -------------------------------
+    lks = lens
+    lqs = [100, 1, 300, 33, 256, 7]
+    qp = torch.randn(sum(lqs), hq, 128, generator=gen).to(BF16)
+    cuq, cuk = _cu(lqs), _cu(lks)
+    op_ref, lsep_ref = ref.flash_attn_varlen_func(qp, kc_small, vc_small, max(lqs), cuq, max(lks), cuk, scale, True,
+                                                  bt_small, return_softmax_lse=True)
+    lsep = torch.zeros(sum(lqs), hq, dtype=torch.float32, device="cuda")
+    op = ops.attn_prefill_varlen(dev(qp), kc, vc, dev(cuq), dev(cuk), max(lqs), scale, block_tables=dev(bt_big), lse=lsep)
+    assert float((op.cpu().float() - op_ref.float()).abs().max()) <= 2e-2 * float(op_ref.float().abs().max()) + 1e-3
+    assert float((lsep.cpu() - lsep_ref).abs().max()) <= 2e-3
+    del kc, vc
+    torch.cuda.empty_cache()
+
+
+# ------------------------------------------------------------------------------------------
 def test_sampler_greedy_exact(ops):
     b, vocab = 37, 151936
     logits = torch.randn(b, vocab, generator=g(70)).to(BF16)
@@ -849,6 +976,40 @@ def test_sampler_replay_with_host_rng(ops):
         e = torch.from_numpy(ops.sample_exponentials_host(1234, 77, r, 0, vocab))
         keys = ref.sampler_keys(logits[r: r + 1], t[r: r + 1], e.unsqueeze(0))[0]
         assert keys[out[r]] >= keys.max() - 1e-3
+
+
+def test_sampler_replay_at_the_real_vocabulary_with_the_restated_draw(ops):
+    """T > 0 at the headline shape: B = 131 rows (the bench's mean decode batch) x V = 151,936, keyed rows (request
+    ordinal | position << 32, as the engine stages them) — every pick must be the argmax of `l/T - log E` with E rebuilt
+    by oracle/philox.py (an independent numpy restatement of the draw, checked against the Philox KATs on CPU), both for
+    the full-row kernel and for 8 vocabulary shards + merge (what a TP = 8 step runs)."""
+    import numpy as np
+    from oracle.philox import race_keys
+    b, vocab, seed = 131, 151936, (5 << 32) | 4242
+    logits = (torch.randn(b, vocab, generator=g(73)) * 2.5).to(BF16)
+    t = torch.tensor([(0.6, 1.0, 0.3, 1.7)[i % 4] for i in range(b)])
+    ordinal = torch.arange(b, dtype=torch.int64) * 3 + 1
+    position = 100 + 7 * torch.arange(b, dtype=torch.int64)
+    position[5] = (1 << 24) + 9                                    # exercises the high counter word of the position
+    keys = ordinal | (position << 32)
+    ws = torch.empty(ops.sample_workspace_bytes(512), dtype=torch.uint8, device="cuda")
+    out = ops.sample(dev(logits), dev(t), seed=seed, offset=0, workspace=ws, row_keys=dev(keys)).cpu()
+    per = vocab // 8
+    packed = torch.zeros(8, 512, 2, dtype=torch.int32, device="cuda")
+    dl = dev(logits)
+    for r in range(8):
+        ops.sample_shard(dl[:, r * per:(r + 1) * per].contiguous(), dev(t), r * per, seed, 0, ws, packed[r],
+                         row_keys=dev(keys))
+    merged = ops.sample_merge(packed, 8, b, torch.empty(b, dtype=torch.int64, device="cuda")).cpu()
+    assert torch.equal(merged, out)
+    lf = logits.float().numpy()
+    exact = 0
+    for r in range(b):
+        k = race_keys(lf[r], float(t[r]), seed, int(ordinal[r]), int(position[r]))
+        assert k[int(out[r])] >= k.max() - 2e-4, (r, int(out[r]), int(k.argmax()))
+        exact += int(out[r]) == int(k.argmax())
+    assert exact >= b - 1                                          # (a last-bit tie between hardware log and numpy's)
+    assert len(set(out.tolist())) > b // 2
 
 
 def test_sampler_distribution(ops):
@@ -974,3 +1135,30 @@ def test_errors_are_reported_not_thrown(ops):
     w = torch.zeros(1004, dtype=BF16, device="cuda")
     with pytest.raises(ops.NvlError, match="multiple of 8"):
         ops.rmsnorm(x, w, 1e-6)
+
+
+def test_decode_plan_is_refused_for_a_launch_it_was_not_built_for(ops):
+    """A plan is a list of per-wave records for ONE (batch, Hkv, max_context): the attention entry points compare the
+    geometry recorded when nvl_decode_plan ran with the launch at hand and refuse a mismatch (the kernel would index the
+    records by wave id and read the wrong segments), as well as a buffer nvl_decode_plan never filled."""
+    bs, hq, hkv, max_ctx = 256, 16, 8, 1024
+    lens = [300, 17, 1024, 5]
+    kc, vc, bt = _paged_setup(lens, hkv, bs, seed=77)
+    kc, vc = dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc))
+    btw = torch.full((len(lens), max_ctx // bs), -1, dtype=torch.int32)
+    btw[:, :bt.shape[1]] = bt
+    ctx = dev(torch.tensor(lens, dtype=torch.int32))
+    q = dev(torch.randn(len(lens), hq, 128, generator=g(78)).to(BF16))
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(8, hq, 4096), dtype=torch.uint8, device="cuda")
+    plan = ops.decode_plan(ctx, hq, hkv, max_ctx)
+    good = ops.paged_attn_decode(q, kc, vc, dev(btw), ctx, 0.088, max_ctx, ws, plan=plan)
+    assert torch.equal(good, ops.paged_attn_decode(q, kc, vc, dev(btw), ctx, 0.088, max_ctx, ws))
+    with pytest.raises(ops.NvlError, match="plan was built for batch=4"):
+        ops.paged_attn_decode(q[:3], kc, vc, dev(btw[:3]), ctx[:3].contiguous(), 0.088, max_ctx, ws, plan=plan)
+    with pytest.raises(ops.NvlError, match="plan was built for"):
+        wide = torch.full((len(lens), 2048 // bs), -1, dtype=torch.int32)
+        wide[:, :btw.shape[1]] = btw
+        ops.paged_attn_decode(q, kc, vc, dev(wide), ctx, 0.088, 2048, ws, plan=plan)
+    stray = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ops.NvlError, match="not produced by nvl_decode_plan"):
+        ops.paged_attn_decode(q, kc, vc, dev(btw), ctx, 0.088, max_ctx, ws, plan=stray)

@@ -201,6 +201,30 @@ def test_tp2_engine_greedy_parity_on_one_gpu(tiny_ckpt, mode, monkeypatch):
 
 
 @pytest.mark.timeout(900)
+def test_tp2_engine_sampled_T06_parity_draws_replayed_on_one_gpu(tiny_ckpt, monkeypatch):
+    """T > 0 at TP = 2 inside the captured decode graph: each rank races ITS vocabulary shard (Philox keyed by the GLOBAL
+    column), 8 bytes per row are exchanged, every rank merges — the merged token must be the argmax of `l/T - log E`
+    over the FULL row of the oracle's logits, draws replayed by oracle/philox.py (the reference gathers [B, V] logits
+    to rank 0 and samples there, embed_head.py:62-65 + model_runner.py:212-218)."""
+    from test_e2e_gpu import _check, _judge, _prompts, _run_ours
+    monkeypatch.setenv("NVL_TP_SHARE_GPU", "1")
+    monkeypatch.setenv("NVL_TP_BACKEND", "gloo")
+    monkeypatch.setenv("NVL_TP_PORT", str(_free_port()))
+    monkeypatch.setenv("NVL_TP_P2P", "1")
+    monkeypatch.setenv("NVL_TP_P2P_STRESS_EPOCHS", "100")
+    prompts = _prompts(6, 5, 600, 512, seed=3)
+    max_tokens = [24, 40, 8, 33, 1, 17]
+    temps = [0.6, 0.6, 1.0, 0.0, 0.6, 1.3]
+    outs, rec, nblk = _run_ours(tiny_ckpt, prompts, max_tokens, temperatures=temps, enforce_eager=False,
+                                max_model_len=2048, num_kvcache_blocks=32, max_num_seqs=16, tensor_parallel_size=2,
+                                seed=77)
+    assert [len(o["token_ids"]) for o in outs] == max_tokens
+    v = _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, temperatures=temps, seed=77, max_num_seqs=16)
+    _check("tiny TP=2 p2p-graph T>0", v, sum(max_tokens))
+    assert v.sampled_rows == sum(max_tokens) - 33
+
+
+@pytest.mark.timeout(900)
 @pytest.mark.parametrize("tp_size", [4, 8])
 def test_tp4_tp8_engine_greedy_parity_on_one_gpu(tp_size, monkeypatch):
     """The whole TP engine at degrees 4 and 8 (every rank a process on cuda:0): a 16 / 8-head model shards down to

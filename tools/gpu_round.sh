@@ -61,10 +61,10 @@ tprun)
 tprun2)
   export NVL_BENCH_SHARE_GPU=1 NVL_BENCH_BACKEND=gloo
   for v in "lean" "fenced"; do
-    if [ $v = fenced ]; then export NVL_TP_P2P_FENCES=1; else unset NVL_TP_P2P_FENCES; fi
+    export NVL_TP_P2P_HANDOFF=$v
     T0=$(date +%s); timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29535 bench.py --gpus 2 --tp 2 --steps 1 --warmup 0 --num-seqs 48 --num-kvcache-blocks 300 --no-cpu-baseline > $OUT/torchrun_tp2_$v.json 2> $OUT/torchrun_tp2_$v.err; echo "torchrun tp2 $v rc=$? wall=$(( $(date +%s) - T0 )) s"; grep -v "socket.cpp\|Gloo\|amdgpu.ids\|OMP_NUM\|\*\*\*" $OUT/torchrun_tp2_$v.err | tail -6; cut -c1-700 $OUT/torchrun_tp2_$v.json; echo
   done
-  unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND NVL_TP_P2P_FENCES;;
+  unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND NVL_TP_P2P_HANDOFF;;
 prefillw)
   for w in 4 8; do NVL_PREFILL_WAVES=$w timeout 600 python tools/prefill_bench.py > $OUT/prefill_waves$w.json 2> $OUT/prefill_waves$w.err; echo "prefill waves=$w rc=$?"; cat $OUT/prefill_waves$w.json; echo; done
   NVL_PREFILL_WAVES=8 timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -k "prefill" 2>&1 | tail -3;;
