@@ -266,6 +266,8 @@ bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
     if (col_wgs < 1024) { if (mgroups < 2) mgroups = 2; }
     else mgroups = (mtiles + 8) / 9;
   }
+  // (measured, round 4: a second row group for the SiLU launch as well — 384 workgroups of 5 row tiles instead of 192
+  // of 9 — is SLOWER, 12.0 vs 9.6 us at 131 rows: profiles/r04_gemm_silu_two_row_groups.json)
   int split = 1;
   if (mode == EPI_PARTIAL) {                      // fill the chip: ~256 workgroups
     while (split < 8 && col_wgs * mgroups * split * 2 <= 256 && k % (split * 2 * kNW * 32) == 0) split *= 2;

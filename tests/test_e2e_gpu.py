@@ -268,10 +268,12 @@ def ckpt_06b():
     return path
 
 
-def _oracle_weights_06b(device):
+def _oracle_weights_06b(device, seed=0):
+    """(`dummy_weights=True` engines seed their synthetic weights with Config.seed — the same seed the sampler draws
+    with — so an engine started with seed=s is judged on the weights of seed s.)"""
     from nano_vllm_amd.weights import parameter_shapes, qwen3_config_dict, synth_tensor
     cfg = qwen3_config_dict("qwen3-0.6b")
-    return cfg, {n: synth_tensor(n, s, 0, device=device).cpu() for n, s in parameter_shapes(cfg).items()}
+    return cfg, {n: synth_tensor(n, s, seed, device=device).cpu() for n, s in parameter_shapes(cfg).items()}
 
 
 def test_qwen3_06b_shape_greedy_parity_vs_cpu_oracle_and_device_oracle_agrees(ckpt_06b):
@@ -365,7 +367,7 @@ def test_qwen3_06b_fused_lm_head_sampled_T06_parity(ckpt_06b, monkeypatch):
     max_tokens, temps = [8, 6, 7], [0.6, 0.6, 1.0]
     outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, temperatures=temps, enforce_eager=False,
                                 max_model_len=1024, num_kvcache_blocks=16, max_num_seqs=8, dummy_weights=True, seed=3)
-    cfg, w = _oracle_weights_06b("cuda")
+    cfg, w = _oracle_weights_06b("cuda", seed=3)
     _check("0.6B shapes, fused lm_head, T > 0", _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device="cuda",
                                                             temperatures=temps, seed=3, max_num_seqs=8), sum(max_tokens))
 
