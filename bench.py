@@ -423,6 +423,32 @@ def run_replica(args, torch, dist, rank, world, tp, backend):
 
     runner.prepare_prefill = prepare_prefill_spy
 
+    # ---- where the decode time goes by batch size: the GPU is never idle between decode steps (lookahead), so the
+    #      interval between two consecutive `decode_end` returns is the later step's GPU time
+    by_batch = {}                      # bucket -> [steps, seconds]
+    last_end = [None]
+    orig_end, orig_run_prefill = runner.decode_end, runner._run_prefill
+
+    def decode_end_spy():
+        n = runner._inflight[0][0] if runner._inflight else 0
+        out = orig_end()
+        now = time.perf_counter()
+        if rec["on"] and last_end[0] is not None:
+            b = next(c for c in (8, 16, 32, 64, 96, 128, 160, 192, 224, 256, 1 << 30) if n <= c)
+            acc = by_batch.setdefault(b, [0, 0.0])
+            acc[0] += 1
+            acc[1] += now - last_end[0]
+        last_end[0] = now
+        return out
+
+    def run_prefill_spy(seqs):
+        out = orig_run_prefill(seqs)
+        last_end[0] = None             # the next decode interval would include this prefill
+        return out
+
+    runner.decode_end = decode_end_spy
+    runner._run_prefill = run_prefill_spy
+
     # ---- host-side time of the timed pass. With the decode lookahead (engine/core.py) schedule, postprocess
     #      and prepare_decode of step N+1 run while the GPU executes step N; only fill_tokens is serial. -----
     host = {"schedule_s": 0.0, "postprocess_s": 0.0, "prepare_decode_s": 0.0, "prefill_steps_s": 0.0}
@@ -465,6 +491,10 @@ def run_replica(args, torch, dist, rank, world, tp, backend):
         result["config"]["p2p_handoff"] = tp_mod.handoff_report()
     if rank == 0 and not args.no_roofline and rec["samples"] and tp == 1:
         result["config"]["host_seconds_in_last_step"] = {k: round(v, 4) for k, v in host.items()}
+        result["config"]["decode_ms_per_step_by_batch"] = {
+            (f"<={b}" if b < (1 << 30) else ">256"): {"steps": v[0], "ms_per_step": round(v[1] / v[0] * 1e3, 3),
+                                                       "share_of_decode_time": round(v[1] / max(sum(x[1] for x in by_batch.values()), 1e-9), 3)}
+            for b, v in sorted(by_batch.items())}
         result["roofline"] = roofline_replay(torch, runner, rec, args.model if args.kv_cache_dtype == "bf16" else "no-pmc-pass")
         ds = decode_step_roofline(runner, rec, result, host["prefill_steps_s"])
         result["roofline"]["decode_step"] = ds

@@ -1006,7 +1006,6 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
 #pragma unroll
   for (int c = 0; c < kSpec; ++c)
     if (c < cnt) M = fmaxf(M, m_s[c]);
-  for (int c = kSpec; c < cnt; ++c) M = fmaxf(M, ml[c * 2]);
   float num = 0.f, den = 0.f;
 #pragma unroll
   for (int c = 0; c < kSpec; ++c)
@@ -1015,10 +1014,35 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
       num += f * o_s[c];
       den += f * l_s[c];
     }
-  for (int c = kSpec; c < cnt; ++c) {
-    const float f = exp2f(ml[c * 2] - M);
-    num += f * po[c * 128 + d];
-    den += f * ml[c * 2 + 1];
+  // Segments split over more than kSpec waves (long contexts on few kv heads: 16k tokens on ONE kv head — Qwen3-32B
+  // per rank at TP = 8 — is 125 partials): online over rounds of kBatch slots whose 3 x kBatch loads are all issued
+  // before the first use (the one-load-at-a-time loop this replaces paid a memory round trip per slot, ~60 us at 125
+  // slots). Same value up to fp32 rounding of the running rescale; ordinary segments (<= kSpec slots) are unchanged.
+  constexpr int kBatch = 8;
+  for (int c0 = kSpec; c0 < cnt; c0 += kBatch) {
+    float mb[kBatch], lb[kBatch], ob[kBatch];
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j) {
+      const int c = c0 + j < cnt ? c0 + j : cnt - 1;            // clamped: a valid slot, masked below
+      mb[j] = ml[c * 2];
+      lb[j] = ml[c * 2 + 1];
+      ob[j] = po[c * 128 + d];
+    }
+    float Mb = M;
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j)
+      if (c0 + j < cnt) Mb = fmaxf(Mb, mb[j]);
+    const float r = exp2f(M - Mb);                              // rescale what has been summed so far
+    num *= r;
+    den *= r;
+    M = Mb;
+#pragma unroll
+    for (int j = 0; j < kBatch; ++j)
+      if (c0 + j < cnt) {
+        const float f = exp2f(mb[j] - M);
+        num += f * ob[j];
+        den += f * lb[j];
+      }
   }
   out[row * 128 + d] = (bf16_t)(cnt > 0 ? num / den : 0.f);
   // optional log-sum-exp of the scaled scores (natural log; what flash-attn returns as softmax_lse): the scores are

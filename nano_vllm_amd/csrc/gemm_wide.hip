@@ -53,13 +53,20 @@
 
 namespace {
 
-constexpr int kBK = 128;                 // k per step
+constexpr int kBK = 128;                 // k per step (the 13-16 row-tile form steps by 64: see wide_bk)
 constexpr int kKB = kBK / 32;            // 32-wide MFMA k blocks per step
 enum { EPI_BF16 = 0, EPI_SILU = 1, EPI_PARTIAL = 2 };
 
 __device__ __forceinline__ float silu_f32(float g) { return g / (1.f + __expf(-g)); }
 
-__host__ __device__ constexpr int wide_stages(int mt) { return 3 * mt * 16 * 256 <= 144 * 1024 ? 3 : 2; }
+// k columns per step. 128 (a 256-byte x row per step: one LDS-DMA instruction = 4 rows) up to 12 row tiles. At 13-16 row
+// tiles (ONE row group for 193-256 rows) a 128-wide x tile is 64 KiB: only two of them fit the LDS, the loader can run
+// just ONE step ahead, and every step then waits for a whole L2 round trip of its x tile (round 3: 8B gate_up at 256
+// rows 75.9 us, behind the library's 68.4). Stepping by 64 columns halves the tile (32 KiB: three stages again, the
+// loader two steps = the same 128 columns ahead), at one more barrier per 128 columns. NVL_WIDE_BK=128 keeps the
+// round-3 form for A/B measurements.
+__host__ __device__ constexpr int wide_bk(int mt, int forced) { return forced ? forced : (mt > 12 ? 64 : 128); }
+__host__ __device__ constexpr int wide_stages(int mt, int bk = 128) { return 3 * mt * 16 * bk * 2 <= 144 * 1024 ? 3 : 2; }
 
 // Loader waves per workgroup. One wave keeps at most 63 loads (63 KiB of 1-KiB LDS-DMA instructions) in flight — the
 // vmcnt counter is 6 bits — which at the L2 latency seen under load is ~30 GB/s: in the x-heavy decompositions (few
@@ -70,16 +77,20 @@ __host__ __device__ constexpr int wide_stages(int mt) { return 3 * mt * 16 * 256
 // file and cannot host another wave.
 __host__ __device__ constexpr int wide_loaders(int nw) { return nw == 4 ? 2 : 1; }
 
-template <int MT, int NT, int NW, int EPI, int RING, bool PACKED>
+template <int MT, int NT, int NW, int EPI, int RING, bool PACKED, int BK = 128>
 __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
                                                                      const bf16_t* __restrict__ w,
                                                                      void* __restrict__ out, int M, int N, int K,
                                                                      int steps, int paired_tiles) {
+  static_assert(BK == 128 || BK == 64, "k columns per step");
+  constexpr int kKB = BK / 32;                                    // (shadows the file-scope constants: per-step geometry)
+  constexpr int kBK = BK;
+  constexpr int kRowB = BK * 2;                                   // bytes of one x row per step
   constexpr int kRows = MT * 16;
-  constexpr int kStage = kRows * 256;                             // bytes per LDS stage
-  // x stages: three (the loader runs two steps ahead) while they fit the 160 KiB of LDS — up to 12 row tiles; two (one
-  // step ahead) for 13-16 row tiles, the single-row-group form for 145-256 rows
-  constexpr int NS = wide_stages(MT);
+  constexpr int kStage = kRows * kRowB;                           // bytes per LDS stage
+  // x stages: three (the loader runs two steps ahead) while they fit the 160 KiB of LDS — up to 12 row tiles at 128
+  // columns per step, 16 at 64; two (one step ahead) otherwise
+  constexpr int NS = wide_stages(MT, BK);
   constexpr int AHEAD = NS - 1;
   static_assert(EPI != EPI_SILU || NT == 2, "SiLU: a wave holds a gate tile and its up tile");
   constexpr int GT = EPI == EPI_SILU ? 1 : NT;                    // output tiles per wave
@@ -120,18 +131,25 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
     // l15 of row r holds chunk l15 ^ (r & 15)), so an instruction still reads 4 rows x 256 contiguous bytes.
     // The loads are inline asm (hipcc neither counts them nor keeps M0), so this wave's waits are explicit.
     constexpr int NL = wide_loaders(NW);
-    constexpr int kLC = MT * 4 / NL;                              // 1-KiB pieces of a tile staged by THIS loader wave
-    static_assert((MT * 4) % NL == 0 && kLC * (AHEAD - 1) < 64, "vmcnt is a 6-bit counter");
+    constexpr int kPieceRows = 1024 / kRowB;                      // rows one 1-KiB LDS-DMA instruction covers: 4 (8 at BK = 64)
+    constexpr int kPieces = kRows / kPieceRows;                   // 1-KiB pieces of a tile
+    constexpr int kLC = kPieces / NL;                             // ... staged by THIS loader wave
+    static_assert(kPieces % NL == 0 && kLC * (AHEAD - 1) < 64, "vmcnt is a 6-bit counter");
     const int lw = wave - NW;                                     // which loader: pieces lw, lw + NL, ...
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const bf16_t* xb = x + k0;
     int x_src[kLC];                                               // element offsets (M * K < 2^31)
 #pragma unroll
     for (int i = 0; i < kLC; ++i) {
-      const int row = 4 * (i * NL + lw) + lq;
+      // lane -> (row inside the piece, 16-byte slot of that row) in the LANE-LINEAR image LDS-DMA writes; the chunk the
+      // slot must hold is the consumers' swizzle run backwards (BK = 128: slot ^ (row & 15); BK = 64: slot ^ ((row >> 1) & 7),
+      // two rows share a 256-byte bank row, see frag_off)
+      const int prow = BK == 128 ? lq : lane >> 3, slot = BK == 128 ? l15 : lane & 7;
+      const int row = kPieceRows * (i * NL + lw) + prow;
       int grow = m_base + row;
       grow = grow < M ? grow : M - 1;                             // padding rows read a valid row (never stored)
-      x_src[i] = grow * K + ((l15 ^ (row & 15)) << 3);
+      const int chunk = BK == 128 ? (slot ^ (row & 15)) : (slot ^ ((row >> 1) & 7));
+      x_src[i] = grow * K + (chunk << 3);
     }
     auto issue = [&](int s) {
       const unsigned dst = lds0 + (unsigned)(s % NS) * kStage + (unsigned)lw * 1024;
@@ -193,7 +211,11 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
   }
   int frag_off[kKB];                                              // B fragment of k block kb: row l15 of a row tile
 #pragma unroll
-  for (int kb = 0; kb < kKB; ++kb) frag_off[kb] = l15 * 256 + (((kb * 4 + lq) ^ l15) << 4);
+  for (int kb = 0; kb < kKB; ++kb)
+    frag_off[kb] = BK == 128 ? l15 * 256 + (((kb * 4 + lq) ^ l15) << 4)
+                             // 128-byte rows: rows 2j and 2j + 1 share a 256-byte bank row, so the 16 lanes of a fragment
+                             // read (fixed chunk, rows 0-15) are conflict-free with slot = chunk ^ j
+                             : l15 * 128 + (((kb * 4 + lq) ^ ((l15 >> 1) & 7)) << 4);
 
   f32x4_t acc[MT][NT];
 #pragma unroll
@@ -231,7 +253,7 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
         if (g * PT + t < MT) {
 #pragma unroll
           for (int kb = 0; kb < kKB; ++kb)
-            dst[t][kb] = *reinterpret_cast<const u32x4_t*>(xs + (g * PT + t) * 16 * 256 + frag_off[kb]);
+            dst[t][kb] = *reinterpret_cast<const u32x4_t*>(xs + (g * PT + t) * 16 * kRowB + frag_off[kb]);
         }
     };
     fread(0, f[0]);
@@ -366,17 +388,21 @@ __global__ __launch_bounds__(256) void pack_weight_tiles_kernel(const bf16_t* __
 
 // ---- host: plan ---------------------------------------------------------------------------------------------------
 struct WidePlan {
-  int mt, nt, nw, mgroups, tiles, split, steps;   // tiles = workgroups along N; steps = 128-wide k steps per workgroup
+  int mt, nt, nw, mgroups, tiles, split, steps;   // tiles = workgroups along N; steps = bk-wide k steps per workgroup
+  int bk;                                         // k columns per step: 128, or 64 (wide_bk)
 };
 
 // Weight ring depth. 5 waves (NW = 4) share 4 SIMDs, so those kernels live in 256 registers: one set less at 7+ row
 // tiles x 2 column tiles.
-constexpr int ring_of(int nt, int nw, int mt) {
+constexpr int ring_of128(int nt, int nw, int mt) {
   if (nw == 3) return nt == 1 ? 8 : (mt > 9 ? 4 : 6);   // 4 waves, one per SIMD: 512 registers per wave
   if (mt > 9) return mt == 12 ? 3 : 4;                  // (only NT = 1 is instantiated above 9 row tiles with 5 waves; 12 row
                                                         //  tiles keep three x stages and spill with a deeper ring)
   return nt == 1 ? 6 : (mt >= 7 ? 3 : 4);
 }
+// in steps of `bk` columns: a 64-column step holds half the weight bytes, so the ring is twice as deep for the same
+// bytes in flight (and the same registers)
+constexpr int ring_of(int nt, int nw, int mt, int bk = 128) { return ring_of128(nt, nw, mt) * (128 / bk); }
 
 int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
@@ -402,18 +428,19 @@ double wide_cost(int64_t m, int n, int k, int mode, const WidePlan& p) {
   const double rounds = (double)((wgs + 255) / 256);
   const double wbytes_step = (double)p.nw * p.nt * 16 * 256.0;
   const double t_w = wbytes_step / 28.0e3;                                        // us at 28 GB/s per CU
+  // (the model works in 128-column units; a 64-column plan makes two barriers per unit)
   const double t_mfma = (double)p.mt * p.nt * kKB * 16.0 / 2400.0;               // 16 clk per MFMA at 2.4 GHz
   double t_x = (double)p.mt * 16 * 256.0 / 67.0e3;                                // L2 -> LDS staging of the x tile
-  if (wide_stages(p.mt) == 2 && t_x < 1.1) t_x = 1.1;                            // one step ahead only: an L2 round trip per step
+  if (wide_stages(p.mt, p.bk) == 2 && t_x < 1.1) t_x = 1.1;                      // one step ahead only: an L2 round trip per step
   double t_step = t_w;
   if (t_mfma > t_step) t_step = t_mfma;
   if (t_x > t_step) t_step = t_x;
-  t_step += 0.25 * (t_w < t_x ? t_w : t_x) + 0.05;                                // imperfect overlap + the barrier
+  t_step += 0.25 * (t_w < t_x ? t_w : t_x) + 0.05 * (128 / p.bk);                // imperfect overlap + the barrier(s)
   // the whole chip cannot exceed ~5.6 TB/s either
   const double active = wgs < 256 ? wgs : 256;
   const double chip = active * wbytes_step / 5.6e6;
   if (chip > t_step) t_step = chip;
-  double t = rounds * (p.steps * t_step + 2.0) + 2.5;
+  double t = rounds * (p.steps * (p.bk / 128.0) * t_step + 2.0) + 2.5;
   if (p.split > 1 || mode == EPI_PARTIAL) {
     const double slab = (double)p.split * m * n * 4.0;
     t += slab / 4.0e6;                                                            // written here ...
@@ -429,7 +456,7 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
   if (mode == EPI_SILU ? n % 32 : n % 16) return false;
   const int out_cols = mode == EPI_SILU ? n / 2 : n;
   const int mtiles = (int)((m + 15) / 16);
-  const int ksteps = k / kBK;
+  const int force_bk = env_int("NVL_WIDE_BK", 0) == 128 ? 128 : 0;
   const int force_nt = env_int("NVL_WIDE_NT", 0), force_nw = env_int("NVL_WIDE_NW", 0);
   const int force_split = env_int("NVL_WIDE_SPLIT", 0);
   double best_t = 1e30;
@@ -451,12 +478,14 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
         p.mgroups = (mtiles + mt_max - 1) / mt_max;
         p.mt = round_mt((mtiles + p.mgroups - 1) / p.mgroups, nt);
         if (!p.mt || (p.mt > 9 && !big_ok)) continue;
+        p.bk = wide_bk(p.mt, force_bk);
+        const int ksteps = k / p.bk;
         const int cols = nw * (mode == EPI_SILU ? 1 : nt) * 16;
         p.tiles = (out_cols + cols - 1) / cols;
         for (int split = 1; split <= 32; ++split) {
           if (ksteps % split) continue;
           if (force_split && split != force_split) continue;
-          if (split > 1 && ksteps / split < 2) break;
+          if (split > 1 && ksteps / split < 2 * (128 / p.bk)) break;
           p.split = split;
           p.steps = ksteps / split;
           const double t = wide_cost(m, n, k, mode, p);
@@ -466,20 +495,20 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
     }
   }
   if (best_t < 1e30 && env_int("NVL_WIDE_DEBUG", 0))
-    fprintf(stderr, "nvl_linear_wide plan m=%lld n=%d k=%d mode=%d: nt=%d nw=%d mt=%d groups=%d tiles=%d split=%d steps=%d -> %d wgs, model %.1f us\n",
-            (long long)m, n, k, mode, best->nt, best->nw, best->mt, best->mgroups, best->tiles, best->split, best->steps,
+    fprintf(stderr, "nvl_linear_wide plan m=%lld n=%d k=%d mode=%d: nt=%d nw=%d mt=%d groups=%d tiles=%d split=%d steps=%d x %d -> %d wgs, model %.1f us\n",
+            (long long)m, n, k, mode, best->nt, best->nw, best->mt, best->mgroups, best->tiles, best->split, best->steps, best->bk,
             best->tiles * best->split * best->mgroups, best_t);
   return best_t < 1e30;
 }
 
-template <int MT, int NT, int NW, int EPI, bool PACKED>
+template <int MT, int NT, int NW, int EPI, bool PACKED, int BK>
 int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
-  constexpr int RING = ring_of(NT, NW, MT);
-  const size_t lds = (size_t)wide_stages(MT) * MT * 16 * 256;
+  constexpr int RING = ring_of(NT, NW, MT, BK);
+  const size_t lds = (size_t)wide_stages(MT, BK) * MT * 16 * BK * 2;
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       nvl_set_error("nvl_linear_wide: cannot reserve %zu B of LDS", lds);
       return NVL_ELAUNCH;
@@ -490,11 +519,11 @@ int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, in
   static const bool pair_ok = env_int("NVL_WIDE_PAIR", 1) != 0;
   if (p.mgroups == 2 && pair_ok) {
     const unsigned gx = (unsigned)((p.tiles + 7) / 8) * 16;
-    hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>), dim3(gx, p.split, 1),
+    hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK>), dim3(gx, p.split, 1),
                        dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, p.tiles);
     return NVL_OK;
   }
-  hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED>), dim3(p.tiles, p.split, p.mgroups),
+  hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK>), dim3(p.tiles, p.split, p.mgroups),
                      dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, 0);
   return NVL_OK;
 }
@@ -503,8 +532,13 @@ thread_local bool g_packed = false;      // weight layout of the launch being di
 
 template <int MT, int NT, int NW, int EPI>
 int launch_wide(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
-  return g_packed ? launch_wide_l<MT, NT, NW, EPI, true>(p, x, w, out, m, n, k, s)
-                  : launch_wide_l<MT, NT, NW, EPI, false>(p, x, w, out, m, n, k, s);
+  if constexpr (MT > 12) {                                         // the 64-column step exists for the 13-16 row-tile form only
+    if (p.bk == 64)
+      return g_packed ? launch_wide_l<MT, NT, NW, EPI, true, 64>(p, x, w, out, m, n, k, s)
+                      : launch_wide_l<MT, NT, NW, EPI, false, 64>(p, x, w, out, m, n, k, s);
+  }
+  return g_packed ? launch_wide_l<MT, NT, NW, EPI, true, 128>(p, x, w, out, m, n, k, s)
+                  : launch_wide_l<MT, NT, NW, EPI, false, 128>(p, x, w, out, m, n, k, s);
 }
 
 template <int NT, int NW, int EPI>
