@@ -615,13 +615,20 @@ def pmc_traffic(alg_bytes_per_launch: float, model: str = "qwen3-0.6b", kernel: 
     gfx950, divided by the algorithmic bytes of the same launches; tools/pmc_traffic_update.py). PMC counters cannot
     be read from inside this process, so the ratio measured by that separate pass is applied to this run's bytes
     per launch — it is a property of the kernel's access pattern, not of the run. null when no PMC pass exists
-    for the kernel."""
+    for the kernel, or when the pass was taken on another version of attn_decode.hip (the entry records the source's
+    hash)."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             db = json.load(fh)
         rec = next((v for k, v in db.get("kernels", {}).items() if kernel and kernel.startswith(k)), None)
         if rec is None or model == "no-pmc-pass":
             return None
+        # the ratio belongs to the kernel SOURCE the PMC pass ran: a later edit of attn_decode.hip invalidates it (null
+        # until `tools/gpu_round.sh <tag> pmcg` has been re-run on the new kernel)
+        import hashlib
+        with open(os.path.join(ROOT, "nano_vllm_amd", "csrc", "attn_decode.hip"), "rb") as fh:
+            if hashlib.sha256(fh.read()).hexdigest()[:16] != rec.get("attn_decode_hip_sha16"):
+                return None
         ratio = float(rec["hbm_read_bytes_over_algorithmic"])
     except (OSError, KeyError, ValueError):
         return None

@@ -63,9 +63,13 @@ __device__ __forceinline__ float silu_f32(float g) { return g / (1.f + __expf(-g
 // tiles (ONE row group for 193-256 rows) a 128-wide x tile is 64 KiB: only two of them fit the LDS, the loader can run
 // just ONE step ahead, and every step then waits for a whole L2 round trip of its x tile (round 3: 8B gate_up at 256
 // rows 75.9 us, behind the library's 68.4). Stepping by 64 columns halves the tile (32 KiB: three stages again, the
-// loader two steps = the same 128 columns ahead), at one more barrier per 128 columns. NVL_WIDE_BK=128 keeps the
-// round-3 form for A/B measurements.
-__host__ __device__ constexpr int wide_bk(int mt, int forced) { return forced ? forced : (mt > 12 ? 64 : 128); }
+// loader two steps = the same 128 columns ahead), at one more barrier per 128 columns. Measured at 208 / 256 rows on
+// the SAME decompositions (profiles/r04_gemm_wide_m256_bk64_vs_bk128.json): with one consumer wave per SIMD (NW = 3)
+// 8B gate_up 74.0 -> 61.9 us (library + SiLU 68.1), 32B qkv 54.4 -> 47.7, 32B o 40.8 -> 37.3, 32B gate_up 239 -> 209; it
+// LOSES with four thin consumer waves + two loaders (NW = 4: 8B down 49.9 -> 63.2) and on very deep per-workgroup K
+// ranges (32B down, 6400 columns per workgroup: 131 -> 141) — hence the rule in wide_plan. NVL_WIDE_BK=128 keeps the
+// round-3 form everywhere (A/B measurements).
+__host__ __device__ constexpr bool wide_bk64_pays(int mt, int nw, int k_per_wg) { return mt > 12 && nw == 3 && k_per_wg <= 5120; }
 __host__ __device__ constexpr int wide_stages(int mt, int bk = 128) { return 3 * mt * 16 * bk * 2 <= 144 * 1024 ? 3 : 2; }
 
 // Loader waves per workgroup. One wave keeps at most 63 loads (63 KiB of 1-KiB LDS-DMA instructions) in flight — the
@@ -478,7 +482,9 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
         p.mgroups = (mtiles + mt_max - 1) / mt_max;
         p.mt = round_mt((mtiles + p.mgroups - 1) / p.mgroups, nt);
         if (!p.mt || (p.mt > 9 && !big_ok)) continue;
-        p.bk = wide_bk(p.mt, force_bk);
+        // the decomposition is chosen by the round-3 model in 128-column steps (every plan it picks for the model shapes
+        // has been measured); the k step is refined afterwards, below
+        p.bk = 128;
         const int ksteps = k / p.bk;
         const int cols = nw * (mode == EPI_SILU ? 1 : nt) * 16;
         p.tiles = (out_cols + cols - 1) / cols;
@@ -493,6 +499,10 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
         }
       }
     }
+  }
+  if (best_t < 1e30 && !force_bk && wide_bk64_pays(best->mt, best->nw, best->steps * 128)) {
+    best->bk = 64;
+    best->steps *= 2;
   }
   if (best_t < 1e30 && env_int("NVL_WIDE_DEBUG", 0))
     fprintf(stderr, "nvl_linear_wide plan m=%lld n=%d k=%d mode=%d: nt=%d nw=%d mt=%d groups=%d tiles=%d split=%d steps=%d x %d -> %d wgs, model %.1f us\n",

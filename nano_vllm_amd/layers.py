@@ -348,12 +348,16 @@ def _decode_sized(x: torch.Tensor) -> bool:
 # it is faster than the library GEMM on all but two of the 48 (shape, rows) pairs (each within 2.4 us); at 145-256 rows
 # (one row group of 12 / 16 row tiles, or two paired ones: gemm_wide.hip) it wins on every bf16 and slab-output shape
 # measured (32B down at 256 rows: 130 vs 264 us) and on SiLU outputs while the matrix is moderate (<= 140 MB: the
-# per-rank gate_up shapes; the full-width 8B / 32B gate_up stay on the library, 72.7 vs 67.6 and 240 vs 152 us) —
-# profiles/r03_gemm_wide_m200_m256.json. The same shapes therefore take the same kernel — hence the same bf16
+# per-rank gate_up shapes; at 145-192 rows the full-width 8B / 32B gate_up stay on the library) —
+# profiles/r03_gemm_wide_m200_m256.json. At 193-256 rows the one-row-group form steps K by 64 columns since round 4
+# (gemm_wide.hip::wide_bk64_pays) and takes the 8B gate_up as well (201 MB: 65.0 / 61.9 us at 208 / 256 rows against
+# 74.1 / 68.1 for hipBLASLt + the SiLU launch; the 32B gate_up, 524 MB, stays on the library: 209 vs 161 us) —
+# profiles/r04_gemm_wide_m256_bk64_vs_bk128.json. The same shapes therefore take the same kernel — hence the same bf16
 # rounding — in every run.
 # NVL_GEMM_WIDE=0 never uses it, =1 always (whenever the plan covers the shape), =tune decides by timing both once per
 # (rows, n, k, mode) the first time the shape is seen outside a graph capture (a new device / shape family).
 _WIDE_MAX_BYTES_ABOVE_144_ROWS = {0: float("inf"), 1: 140e6, 2: float("inf")}      # by ops.LINEAR_* mode
+_WIDE_MAX_BYTES_ABOVE_192_ROWS = {0: float("inf"), 1: 256e6, 2: float("inf")}
 _wide_choice: dict[tuple, bool] = {}
 _wide_scratch: dict[tuple, torch.Tensor] = {}
 _flush: dict[int, torch.Tensor] = {}
@@ -414,7 +418,8 @@ def _use_wide(x: torch.Tensor, weight: torch.Tensor, mode: int, packed: torch.Te
     elif policy == "1":
         c = True
     elif policy != "tune":
-        c = m <= 144 or (m <= 256 and n * k * 2 <= _WIDE_MAX_BYTES_ABOVE_144_ROWS[mode])
+        limit = _WIDE_MAX_BYTES_ABOVE_192_ROWS if m > 192 else _WIDE_MAX_BYTES_ABOVE_144_ROWS
+        c = m <= 144 or (m <= 256 and n * k * 2 <= limit[mode])
     elif torch.cuda.is_current_stream_capturing():
         return False                                   # an untimed shape inside a capture: library GEMM, not cached
     else:

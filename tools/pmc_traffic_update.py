@@ -9,6 +9,7 @@ Entry written: kernels[<kernel label>] = {hbm_read_bytes_over_algorithmic, ...}.
 counts HALF the bytes of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM section): doubled here.
 bench.py multiplies a run's algorithmic bytes per launch by this ratio for `roofline.traffic`.
 """
+import hashlib
 import json
 import os
 import sys
@@ -34,7 +35,12 @@ if "kernels" not in db:                         # round-2 layout: one entry at t
     db = {"kernels": {}}
     if "kernel_name" in old:
         db["kernels"][old["kernel_name"]] = old
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+with open(os.path.join(root, "nano_vllm_amd", "csrc", "attn_decode.hip"), "rb") as fh:
+    src_sha = hashlib.sha256(fh.read()).hexdigest()[:16]
 db["kernels"][label] = {
+    # the kernel source this pass measured: bench.py applies the ratio only while attn_decode.hip still hashes to this
+    "attn_decode_hip_sha16": src_sha,
     "source": f"{os.path.basename(summary)} (rocprofv3 --pmc FETCH_SIZE --kernel-include-regex decode_ -- python "
               f"tools/attn_replay.py --fused --reps 1 ...)",
     "model": model, "dispatches": main["dispatches"],
