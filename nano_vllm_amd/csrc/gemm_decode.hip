@@ -28,6 +28,7 @@
 //   SILU    out[m, j]            = bf16(silu(bf16(acc[gate j])) * bf16(acc[up j]))   (activation.py:8-11)
 //   PARTIAL part[split][m, n]    = acc (fp32), summed and rounded by the consumer
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -271,6 +272,20 @@ bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
   int split = 1;
   if (mode == EPI_PARTIAL) {                      // fill the chip: ~256 workgroups
     while (split < 8 && col_wgs * mgroups * split * 2 <= 256 && k % (split * 2 * kNW * 32) == 0) split *= 2;
+  }
+  // A/B override for tools/gemm_skinny_sweep.py: NVL_SKINNY_PLAN="nt,mgroups,split" (0 = keep the rule's value)
+  if (const char* e = getenv("NVL_SKINNY_PLAN")) {
+    int f_nt = 0, f_mg = 0, f_sp = 0;
+    if (sscanf(e, "%d,%d,%d", &f_nt, &f_mg, &f_sp) >= 1) {
+      if (f_nt == 1 || f_nt == 2) {
+        if (mode == EPI_SILU && f_nt != 2) return false;
+        if (f_nt == 2 && mode != EPI_SILU && tiles % 2) return false;
+        nt = f_nt;
+      }
+      if (f_mg > 0) mgroups = f_mg;
+      if (f_sp > 0 && mode == EPI_PARTIAL) split = f_sp;
+      if (mgroups > mtiles) return false;
+    }
   }
   if (k % (split * kNW * 32)) return false;
   const int kw = k / (split * kNW * 32);          // 32-wide k blocks per wave
