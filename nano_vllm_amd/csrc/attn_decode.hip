@@ -113,7 +113,7 @@ struct PlanHeader {          // 32 bytes, followed by nwaves PlanEntry records
 struct __attribute__((aligned(16))) PlanEntry { int32_t b, h, t0, nb; };   // first segment of a wave's share (b < 0: none)
 
 __global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restrict__ ctx, int batch, int hkv, int nwaves,
-                                                          int min_tiles, PlanHeader* __restrict__ hdr) {
+                                                          PlanHeader* __restrict__ hdr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int* wsum = reinterpret_cast<int*>(smem_raw);
   int* pre = wsum + kWaves;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restr
   __syncthreads();
   const int64_t total = (int64_t)pre[batch] * hkv;
   int64_t per = (total + nwaves - 1) / nwaves;
-  if (per < min_tiles) per = min_tiles;
+  if (per < kMinTilesPerWave) per = kMinTilesPerWave;
   if (threadIdx.x == 0) {
     hdr->total = total;
     hdr->per = per;
@@ -1050,19 +1050,11 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
   if (lse != nullptr && d == 0) lse[row] = cnt > 0 ? 0.6931471805599453f * (M + log2f(den)) : -INFINITY;
 }
 
-// Minimum share of a wave in the PLANNED launches (the self-scheduling kernels keep kMinTilesPerWave): it bounds the
-// split partials per (b, h) segment and therefore sizes the workspace. NVL_DECODE_MIN_TILES (2 ... 4, A/B knob): a
-// smaller share spreads SMALL steps (few kv heads, short contexts: Qwen3-32B per rank at TP = 8 has ~3,700 tiles for
-// 2,048 waves) over more waves at the price of more partials.
-inline int plan_min_tiles() {
-  static const int v = [] {
-    const char* e = getenv("NVL_DECODE_MIN_TILES");
-    const int x = e && *e ? atoi(e) : kMinTilesPerWave;
-    return x < 1 ? 1 : (x > kMinTilesPerWave ? kMinTilesPerWave : x);
-  }();
-  return v;
-}
-inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * plan_min_tiles())) + 2; }
+// (A smaller minimum share per wave for small steps — 2 tiles instead of kMinTilesPerWave = 4, tried in round 4 on the
+// one-kv-head shape of Qwen3-32B per rank at TP = 8 — moves 1.2 us from the main kernel into the split merge, which then
+// has twice the partials: 19.1 + 4.5 -> 18.0 + 5.6 us per launch, nothing on the bench shape.
+// profiles/r04_decode_min_tiles_ab.json)
+inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 2; }
 
 // LDS and grid of decode_mfma8_kernel — shared by its launcher and by nvl_decode_plan, whose per-wave records are only
 // valid for the grid they were made for. `prefix_batch`: sequences whose tile prefix the kernel keeps in LDS (0 with a plan).
@@ -1073,8 +1065,7 @@ inline int64_t mfma8_grid(int64_t batch, int hkv, int64_t max_context, bool plan
   const size_t lds = mfma8_lds_bytes(planned ? 0 : batch);
   int64_t grid = (int64_t)nvl_device_cu_count() * (2 * lds <= 160 * 1024 ? 2 : 1);
   const int64_t max_tiles = batch * hkv * ((max_context + kTile - 1) / kTile);
-  const int mt = planned ? plan_min_tiles() : kMinTilesPerWave;
-  const int64_t max_wg = (max_tiles + kWaves * mt - 1) / (kWaves * mt);
+  const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
   if (grid > max_wg) grid = max_wg;
   return grid < 1 ? 1 : grid;
 }
@@ -1409,7 +1400,7 @@ extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int n
     attr_set = true;
   }
   hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, context_lens, (int)batch,
-                     num_kv_heads, nwaves, plan_min_tiles(), (PlanHeader*)plan);
+                     num_kv_heads, nwaves, (PlanHeader*)plan);
   plan_shadow_put(plan, batch, num_kv_heads, max_context);
   return nvl_check_launch(who);
 }

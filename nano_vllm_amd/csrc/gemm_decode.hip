@@ -257,8 +257,11 @@ bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
   if (k > 4096 || (k > 1024 && mode != EPI_PARTIAL) || (k > 3072 && mode == EPI_PARTIAL)) return false;   // deep K
   // two column tiles per workgroup (every x fragment feeds 2 MFMAs) and M split in >= 2 groups once there
   // are enough rows: halves the x bytes a CU ingests at the same workgroup count
+  // (round 4 sweep of every (NT, row groups, split) decomposition on the four Qwen3-0.6B projections at 64 / 131 / 208 rows,
+  // GEMM + the add-RMSNorm that sums its slabs: tools/gemm_skinny_sweep.py, profiles/r04_gemm_skinny_sweep.jsonl — the
+  // two-tile / two-row-group form already pays from 4 row tiles on: qkv 5.5 -> 4.9 us, down 7.5 -> 7.1, o 6.7 -> 6.5 at 64 rows)
   int nt = 1;
-  if (mode == EPI_SILU || (mtiles > 8 && tiles % 2 == 0)) nt = 2;
+  if (mode == EPI_SILU || (mtiles >= 4 && tiles % 2 == 0)) nt = 2;
   int mgroups = (mtiles + 15) / 16;
   const int col_wgs = mode == EPI_SILU ? tiles : tiles / nt;
   if (nt == 2 && mode != EPI_SILU) {
@@ -269,6 +272,10 @@ bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
   }
   // (measured, round 4: a second row group for the SiLU launch as well — 384 workgroups of 5 row tiles instead of 192
   // of 9 — is SLOWER, 12.0 vs 9.6 us at 131 rows: profiles/r04_gemm_silu_two_row_groups.json)
+  // o_proj-like slab outputs (K <= 2048) from 9 row tiles on: THREE row groups x a 2-way K split (192 workgroups, two
+  // slabs for the norm to sum) beat two groups x 4-way (256 workgroups, four slabs): 8.2 -> 7.7 us at 131 rows, 9.6 -> 9.2
+  // at 208 (same sweep); deeper K (down_proj, 3072) has no single-pass 2-way split and stays as it was
+  if (mode == EPI_PARTIAL && nt == 2 && col_wgs < 1024 && mtiles >= 9 && k <= 2048 && k % (2 * kNW * 32) == 0) mgroups = 3;
   int split = 1;
   if (mode == EPI_PARTIAL) {                      // fill the chip: ~256 workgroups
     while (split < 8 && col_wgs * mgroups * split * 2 <= 256 && k % (split * 2 * kNW * 32) == 0) split *= 2;

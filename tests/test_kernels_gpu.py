@@ -99,7 +99,7 @@ def _lin_inputs(m, n, k, seed):
     return x, w, x.float() @ w.float().t()
 
 
-@pytest.mark.parametrize("m", [1, 7, 16, 131, 144, 256, 300])
+@pytest.mark.parametrize("m", [1, 7, 16, 48, 64, 100, 131, 144, 256, 300])
 @pytest.mark.parametrize("n,k", LINEAR_SHAPES)
 def test_linear_decode_bf16(ops, m, n, k):
     x, w, acc = _lin_inputs(m, n, k, 20)
@@ -126,7 +126,7 @@ def test_linear_decode_silu(ops, m, n, k):
     assert float((ref.bf16_ulp_diff(y.cpu(), want) > 1).float().mean()) < 0.02
 
 
-@pytest.mark.parametrize("m", [1, 16, 131, 144, 256, 300])
+@pytest.mark.parametrize("m", [1, 16, 64, 100, 131, 144, 208, 256, 300])
 @pytest.mark.parametrize("n,k", [(1024, 2048), (1024, 3072), (256, 512), (512, 256)])
 def test_linear_decode_partials_into_add_rmsnorm(ops, m, n, k):
     """o_proj / down_proj as fp32 split-K partials + the fused slab-sum/add/RMSNorm consumer."""
