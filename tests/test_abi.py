@@ -62,7 +62,8 @@ def test_host_side_argument_validation_without_gpu():
     assert rc == -1 and b"plan buffer" in lib.nvl_last_error()
     # skinny linear: shape coverage is a query, an uncovered shape is EUNSUPPORTED (-3), never a silent fallback
     assert lib.nvl_linear_decode_splits(144, 4096, 1024, 0) == 1
-    assert lib.nvl_linear_decode_splits(144, 1024, 2048, 2) == 4
+    assert lib.nvl_linear_decode_splits(144, 1024, 2048, 2) == 2      # (three row groups x a 2-way K split from 9 row tiles on)
+    assert lib.nvl_linear_decode_splits(64, 1024, 2048, 2) == 4
     assert lib.nvl_linear_decode_splits(144, 6144, 1024, 1) == 1
     assert lib.nvl_linear_decode_splits(144, 6144, 4096, 0) == 0          # deep-K shapes: not this kernel's (nvl_linear_wide)
     # collectives: a communicator must be created and connected first; lm_head sampler reports uncovered shapes

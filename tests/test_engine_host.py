@@ -324,8 +324,11 @@ def test_decode_gemm_chooser_policies(monkeypatch):
     assert layers.decode_linear(xd, deep, ops.LINEAR_BF16) == "wide"                        # 16 rows: one row group
     x200 = torch.zeros(200, 4096)
     assert layers.decode_linear(x200, deep, ops.LINEAR_BF16) == "wide"                      # two row groups, small matrix
-    huge = torch.zeros(20480, 4096)                                                         # 168 MB gate|up: library GEMM
-    assert layers.decode_linear(x200, huge, ops.LINEAR_SILU) is None
+    huge = torch.zeros(20480, 4096)                                                         # 168 MB gate|up
+    x176 = torch.zeros(176, 4096)
+    assert layers.decode_linear(x176, huge, ops.LINEAR_SILU) is None                        # 145-192 rows: library GEMM
+    assert layers.decode_linear(x200, huge, ops.LINEAR_SILU) == "wide"                      # 193-256 rows: 64-column k step
+    assert layers.decode_linear(x200, torch.zeros(40960, 4096), ops.LINEAR_SILU) is None    # 336 MB gate|up: library GEMM
     assert layers.decode_linear(x200, huge, ops.LINEAR_BF16) == "wide"
     # tune: timed outside a capture, deferred (not cached) inside one
     layers._wide_choice.clear()
