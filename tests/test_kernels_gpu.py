@@ -1159,6 +1159,8 @@ def test_decode_plan_is_refused_for_a_launch_it_was_not_built_for(ops):
         wide = torch.full((len(lens), 2048 // bs), -1, dtype=torch.int32)
         wide[:, :btw.shape[1]] = btw
         ops.paged_attn_decode(q, kc, vc, dev(wide), ctx, 0.088, 2048, ws, plan=plan)
+    # a buffer this step's nvl_decode_plan never filled: unknown to the library — or, when the allocator hands out an
+    # address an earlier plan lived at, known with THAT plan's geometry; refused either way
     stray = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device="cuda")
-    with pytest.raises(ops.NvlError, match="not produced by nvl_decode_plan"):
+    with pytest.raises(ops.NvlError, match="not produced by nvl_decode_plan|plan was built for"):
         ops.paged_attn_decode(q, kc, vc, dev(btw), ctx, 0.088, max_ctx, ws, plan=stray)
