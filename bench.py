@@ -17,8 +17,10 @@ Rank 0 prints ONE JSON line. Besides the driver's fields it carries
                  bytes per launch (sum_b len_b * 2 * Hkv * 128 * 2 B) / mean launch time, measured
                  with HIP events on the launch stream by replaying decode batches recorded during
                  the timed pass (every 8th step: real context lengths and block tables, all 28
-                 layer caches) — launches inside the captured hipGraph cannot be bracketed
-                 individually. The rocprofv3 kernel-trace summary of this command is in profiles/.
+                 layer caches): the engine's own step graph cannot be bracketed per kernel, so each
+                 recorded step's 28 attention launches (main kernel + split merge) are captured into
+                 a hipGraph of their own and the events bracket its replay. The rocprofv3
+                 kernel-trace summary of this command is in profiles/.
   cpu_baseline : the CPU oracle (oracle/engine.py, a port of the reference's path) timed on this
                  box's host cores on a bounded sample of the same seeded workload (first 16 sequences).
   parity       : the engine's own T = 0.6 tokens on that sample, judged exactly against the oracle's
@@ -570,7 +572,7 @@ def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
             "kernel": kernel + " + decode_stream_combine_kernel (nvl_paged_attn_decode_fused: the launch the decode"
                       " step makes)",
             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],
-            "launches_timed": r["launches_timed"], "decode_steps_in_pass": rec["steps"],
+            "launches_timed": r["launches_timed"], "launched": r["launched"], "decode_steps_in_pass": rec["steps"],
             "kv_bytes_read_in_pass": step_bytes, "frac_of_measured_achievable_6.29TBps": achieved / 6290.0}
 
 

@@ -67,7 +67,7 @@ def bench_decode_batches(num_seqs: int = 256, num_blocks: int = 9380, every: int
 
 
 def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: int = 2, fused: bool = False,
-           plan: bool = True):
+           plan: bool = True, graph: bool = True):
     """Time nvl_paged_attn_decode (main kernel + split combine) on the recorded batches.
     kv_cache: [2, L, num_blocks, Hkv, block, 128]. Block ids are folded into the cache with a
     modulo when the cache is smaller than the pool the schedule was recorded with.
@@ -95,8 +95,8 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
         bt_d = torch.from_numpy(np.ascontiguousarray(bt)).to(dev)
         q = q_all[:n]
         step_plan = ops.decode_plan(ctx_d, hq, hkv, max_ctx) if plan else None
-        for _ in range(reps):                       # keep the last rep (caches are 100s of MB: nothing stays warm)
-            start.record()
+
+        def layers():
             for layer in range(L):
                 if fused:
                     ops.paged_attn_decode_fused(qkv_all[:n], nw, nw, 1e-6, table, kv_cache[0, layer], kv_cache[1, layer],
@@ -104,13 +104,30 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
                 else:
                     ops.paged_attn_decode(q, kv_cache[0, layer], kv_cache[1, layer], bt_d, ctx_d, scale, max_ctx, ws,
                                           out=out[:n], plan=step_plan)
+
+        # The L launches of a step are captured into ONE hipGraph and the replay is timed (as the engine runs them:
+        # inside its captured decode step) — issued eagerly from Python, two short launches per layer are host-bound
+        # (3-4 us of launch cost each: the one-kv-head shape measured 33 us per call eagerly against 19 + 4.5 us of
+        # kernel time under rocprofv3) and the bracket would time the host, not the kernel.
+        runner = layers
+        if graph:
+            layers()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                layers()
+            runner = g.replay
+        for _ in range(reps):                       # keep the last rep (caches are 100s of MB: nothing stays warm)
+            start.record()
+            runner()
             stop.record()
             torch.cuda.synchronize()
         total_ms += start.elapsed_time(stop)
         total_bytes += int(ctx.sum()) * 2 * hkv * 128 * kv_cache.element_size() * L
         launches += L
     return dict(achieved_GBps=total_bytes / (total_ms * 1e-3) / 1e9, algorithmic_bytes_per_launch=total_bytes / launches,
-                avg_launch_us=total_ms * 1e3 / launches, launches_timed=launches, reps=reps)
+                avg_launch_us=total_ms * 1e3 / launches, launches_timed=launches, reps=reps,
+                launched="one captured hipGraph per step (L layer launches), replayed" if graph else "eagerly from Python")
 
 
 def main():
@@ -123,6 +140,8 @@ def main():
     ap.add_argument("--pool-blocks", type=int, default=9380, help="KV pool the schedule is recorded with")
     ap.add_argument("--fused", action="store_true", help="time nvl_paged_attn_decode_fused (norm+rope+store inside)")
     ap.add_argument("--no-plan", action="store_true", help="every launch derives its own schedule (no nvl_decode_plan)")
+    ap.add_argument("--eager", action="store_true", help="issue the launches eagerly from Python instead of replaying one "
+                                                         "captured graph per step (host-bound for short launches)")
     ap.add_argument("--layer-major", action="store_true", help="cache laid out [L, 2, blocks, ...] instead of [2, L, blocks, ...]")
     ap.add_argument("--fp8", action="store_true", help="OCP fp8 e4m3 KV cache (opt-in extension; 128-byte rows)")
     ap.add_argument("--cache-blocks", type=int, default=0,
@@ -147,7 +166,8 @@ def main():
             kv8[:, layer, :used] = kv[:, layer, :used].to(torch.float8_e4m3fn)
         kv = kv8
     ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(512, args.hq, 4096), dtype=torch.uint8, device=dev)
-    r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps, fused=args.fused, plan=not args.no_plan)
+    r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps, fused=args.fused, plan=not args.no_plan,
+               graph=not args.eager)
     r.update(stats, kernel=f"decode<G={args.hq // args.hkv}, fused={str(args.fused).lower()}, kv={'fp8' if args.fp8 else 'bf16'}>", kv_blocks_used=nblk, samples=len(samples),
              frac_of_8TBps=r["achieved_GBps"] / 8000.0)
     print(json.dumps(r), flush=True)
