@@ -50,7 +50,14 @@ constexpr int kTileBytes = kKBlk * (kKRowB + kVRowB);   // one K + V tile pair i
 // NW = 8: one workgroup = 8 waves = the same 128 query rows of TWO q-heads of one kv group (waves 0-3 / 4-7): the
 //         K/V tile is fetched from L2/HBM and written to LDS once for both heads — half the staging loads, LDS
 //         writes and prologue work per MFMA, at the price of an 8-wave barrier domain (one workgroup per CU).
-template <bool PAGED, bool KV8, int NW>
+// PERSIST (4 waves, XCD-aware numbering, <= 64 sequences: every prefill batch of short prompts): a workgroup does not
+//         end with its (sequence, q-head, q-block) item but walks on through the item list — grid = 2 workgroups per
+//         CU, workgroup b takes items b, 2 grid - 1 - b, 2 grid + b, ... (a snake over the longest-first list, so the sums
+//         balance) — and, during the LAST key tile of an item, already requests the next item's Q rows and first K/V
+//         tile: the per-item fixed cost of a short sequence's workgroup (dispatch, the cu_seqlens round trip, the Q and
+//         first-tile round trip, the store tail — about half of its ~25 us at the bench's prompt lengths) shrinks to the
+//         epilogue arithmetic. The tile list stays in registers for the whole launch.
+template <bool PAGED, bool KV8, int NW, bool PERSIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_tok_stride,
     int64_t v_tok_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
@@ -80,46 +87,54 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   // side by side at the same pace and all but the first hit that XCD's L2 (cdna_hip_programming.md T1; placement
   // only changes speed, never results).
   int head, tile_rank;
-  if (xcd_map) {
+  // block id -> (q-head, rank of the tile in the longest-first list) under the XCD-aware numbering
+  auto xcd_decode = [&](int b, int& head_, int& rank_) {
     const int G = hq / hkv;
-    const int b = blockIdx.x, xcd = b & 7, slot = b >> 3;
+    const int xcd = b & 7, slot = b >> 3;
     const int gi = slot / G, g = slot - gi * G;
     const int j = gi * 8 + xcd;                    // (tile, kv-head) group, longest tiles first
-    tile_rank = j / hkv;
-    head = (j - tile_rank * hkv) * G + g;
+    rank_ = j / hkv;
+    head_ = (j - rank_ * hkv) * G + g;
+  };
+  if (xcd_map) {
+    xcd_decode(blockIdx.x, head, tile_rank);
   } else {
     head = NW == 8 ? blockIdx.x * 2 + hsub : blockIdx.x;
     tile_rank = blockIdx.y;
   }
   // ---- which (sequence, q-block) is this workgroup? ------------------------------------
   int seq, qblk, q0, lq, k0, lk;     // wave-uniform
-  if (num_seqs <= 64) {
+  // the tile list in registers (launches of <= 64 sequences): lane i holds sequence i's bounds and tile prefix
+  int a0 = 0, a1 = 0, b0 = 0, b1 = 0, val = 0, sc = 0, total = 0;
+  auto reg_locate = [&](int rank_, int& seq_, int& qblk_, int& q0_, int& lq_, int& k0_, int& lk_) {
+    const int tile = total - 1 - rank_;            // longest-first, see above
+    seq_ = __popcll(__ballot(sc <= tile));         // inclusive prefixes <= tile: the sequences before ours
+    qblk_ = tile - __builtin_amdgcn_readlane(sc - val, seq_);
+    q0_ = __builtin_amdgcn_readlane(a0, seq_);
+    lq_ = __builtin_amdgcn_readlane(a1, seq_) - q0_;
+    k0_ = __builtin_amdgcn_readlane(b0, seq_);
+    lk_ = __builtin_amdgcn_readlane(b1, seq_) - k0_;
+  };
+  if (PERSIST || num_seqs <= 64) {
     // Up to 64 sequences (every prefill batch of the bench): each WAVE derives the tile list by itself, in
     // registers — lane i holds sequence i's cu_seqlens entries, a shuffle scan gives the tile prefix, a ballot finds
     // the sequence, readlane fetches its bounds. One global round trip, no LDS, no workgroup barrier, no dependent
     // re-load of cu_seqlens[seq] (the LDS form below costs three barriers, a binary search out of LDS and a second
     // dependent round trip per workgroup: ~1 us of a short sequence's ~5 us workgroup).
-    int a0 = 0, a1 = 0, b0 = 0, b1 = 0;
     if (lane < num_seqs) {
       a0 = cu_q[lane]; a1 = cu_q[lane + 1];
       b0 = cu_k[lane]; b1 = cu_k[lane + 1];
     }
-    const int val = (a1 - a0 + kQBlk - 1) / kQBlk;
-    int sc = val;
+    val = (a1 - a0 + kQBlk - 1) / kQBlk;
+    sc = val;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const int n = __shfl_up(sc, o, 64);
       if (lane >= o) sc += n;
     }
-    const int total = __builtin_amdgcn_readlane(sc, 63);
+    total = __builtin_amdgcn_readlane(sc, 63);
     if (tile_rank >= total) return;  // grid is an upper bound
-    const int tile = total - 1 - tile_rank;        // longest-first, see above
-    seq = __popcll(__ballot(sc <= tile));          // inclusive prefixes <= tile: the sequences before ours
-    qblk = tile - __builtin_amdgcn_readlane(sc - val, seq);
-    q0 = __builtin_amdgcn_readlane(a0, seq);
-    lq = __builtin_amdgcn_readlane(a1, seq) - q0;
-    k0 = __builtin_amdgcn_readlane(b0, seq);
-    lk = __builtin_amdgcn_readlane(b1, seq) - k0;
+    reg_locate(tile_rank, seq, qblk, q0, lq, k0, lk);
   } else {
     int carry = 0;
     if (tid == 0) pre[0] = 0;
@@ -171,21 +186,29 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   k0 = __builtin_amdgcn_readfirstlane(k0);
   lk = __builtin_amdgcn_readfirstlane(lk);
   head = __builtin_amdgcn_readfirstlane(head);   // (8-wave shape: derived from the wave id, uniform per wave)
-  const int kvh = head / (hq / hkv);
-
-  const int off = lk - lq;  // bottom-right alignment: query i sees keys j <= i + off
-  const int qi = qblk * kQBlk + wave * 32 + qcol;
-  const bool q_valid = qi < lq;
-  const int qi_c = q_valid ? qi : lq - 1;
-  const int kv_end = min(lk, qblk * kQBlk + kQBlk + off);  // keys visible to the block's last query
+  // geometry of the CURRENT item (assigned once; PERSIST: again at every item switch)
+  int kvh, off, qi, qi_c, kv_end;
+  bool q_valid;
+  auto item_geometry = [&]() {
+    kvh = head / (hq / hkv);
+    off = lk - lq;  // bottom-right alignment: query i sees keys j <= i + off
+    qi = qblk * kQBlk + wave * 32 + qcol;
+    q_valid = qi < lq;
+    qi_c = q_valid ? qi : lq - 1;
+    kv_end = min(lk, qblk * kQBlk + kQBlk + off);  // keys visible to the block's last query
+  };
+  item_geometry();
 
   // ---- Q fragments: B operand of S^T = K.Q^T : lane (query, hi) holds d = ds*16 + 8*hi .. +8
   bf16x8_t qf[8];
-  {
-    const bf16_t* qp = q + ((int64_t)(q0 + qi_c) * hq + head) * 128 + hi * 8;
+  auto load_q = [&](int q0_, int lq_, int qblk_, int head_) {
+    int row = qblk_ * kQBlk + wave * 32 + qcol;
+    row = row < lq_ ? row : lq_ - 1;
+    const bf16_t* qp = q + ((int64_t)(q0_ + row) * hq + head_) * 128 + hi * 8;
 #pragma unroll
     for (int ds = 0; ds < 8; ++ds) qf[ds] = as_bf16x8(*reinterpret_cast<const u32x4_t*>(qp + ds * 16));
-  }
+  };
+  load_q(q0, lq, qblk, head);
   // Keep the Q loads ahead of the first tile's staging loads: the prologue's wait for that tile then also
   // retires them. (If hipcc sinks them to the loop head, its waitcnt pass keeps per-fragment vmcnt waits
   // inside the loop, which drain the in-flight staging loads in the middle of every QK^T phase.)
@@ -198,7 +221,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
   float m_run = kNegBig, l_run = 0.f;
 
-  const int kmax_vis = qi_c + off;  // last key this query may see
+  int kmax_vis = qi_c + off;  // last key this query may see
   // loop-invariant LDS byte offsets of this lane's K fragments (row qcol, swizzled slot) and V transpose reads
   int kslot[8];
 #pragma unroll
@@ -225,12 +248,13 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   // offsets above): no per-tile address VALU, nothing the loads depend on is rewritten while they are in
   // flight, and rows past the end of the sequence / block come back as zeros from the hardware range check
   // (they are masked anyway).
-  auto stage_load = [&](int kt) {       // issue the global loads of the tile starting at key kt
+  // issue the global loads of the tile starting at key kt of the item (sequence seq_, kv-head kvh_, keys k0_ .. k0_ + lk_)
+  auto stage_load_of = [&](int seq_, int kvh_, int k0_, int lk_, int kt) {
     __amdgpu_buffer_rsrc_t krs, vrs;
     int ksoff, vsoff;
     if constexpr (PAGED) {
-      const int blk = block_tables[(int64_t)seq * bt_stride + kt / block_size];
-      const int64_t base = (((int64_t)blk * hkv + kvh) * block_size + (kt % block_size)) * 128;
+      const int blk = block_tables[(int64_t)seq_ * bt_stride + kt / block_size];
+      const int64_t base = (((int64_t)blk * hkv + kvh_) * block_size + (kt % block_size)) * 128;
       if constexpr (KV8) {
         krs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)k + base), 0, kKBlk * 128, 0x00020000);
         vrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)v + base), 0, kKBlk * 128, 0x00020000);
@@ -240,10 +264,10 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
       }
       ksoff = vsoff = 0;
     } else {
-      krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)k0 * k_tok_stride + kvh * 128), 0,
-                                              (int)(lk * kstride * 2), 0x00020000);
-      vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)k0 * v_tok_stride + kvh * 128), 0,
-                                              (int)(lk * vstride * 2), 0x00020000);
+      krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)k0_ * k_tok_stride + kvh_ * 128), 0,
+                                              (int)(lk_ * kstride * 2), 0x00020000);
+      vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)k0_ * v_tok_stride + kvh_ * 128), 0,
+                                              (int)(lk_ * vstride * 2), 0x00020000);
       ksoff = (int)(kt * kstride * 2);
       vsoff = (int)(kt * vstride * 2);
     }
@@ -262,6 +286,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
       }
     }
   };
+  auto stage_load = [&](int kt) { stage_load_of(seq, kvh, k0, lk, kt); };
   auto stage_write = [&](int buf) {     // registers -> LDS tile buffer `buf`
     unsigned char* kl = smem + buf * kTileBytes;
     unsigned char* vl = kl + kKBlk * kKRowB;
@@ -291,9 +316,15 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   // keys this WAVE's 32 rows can see: tiles starting above wave_kmax carry no work for it
   // (a wave whose 32 rows all lie past the end of the sequence — the tail of the last q-block — has no work at all:
   // it only helps staging the tiles; +3-4 % on batches of short sequences)
-  const bool wave_has_rows = qblk * kQBlk + wave * 32 < lq;
-  const int wave_kmax = wave_has_rows ? min(qblk * kQBlk + wave * 32 + 31, lq - 1) + off : -1;
-  const int wave_kmin = min(qblk * kQBlk + wave * 32, lq - 1) + off;   // ... and all of them see keys <= wave_kmin
+  int wave_kmax_s, wave_kmin_s;         // wave-uniform copies on the scalar side (scalar branches instead of exec masks)
+  auto wave_frontier = [&]() {
+    const bool wave_has_rows = qblk * kQBlk + wave * 32 < lq;
+    const int wave_kmax = wave_has_rows ? min(qblk * kQBlk + wave * 32 + 31, lq - 1) + off : -1;
+    const int wave_kmin = min(qblk * kQBlk + wave * 32, lq - 1) + off;   // ... and all of them see keys <= wave_kmin
+    wave_kmax_s = __builtin_amdgcn_readfirstlane(wave_kmax);
+    wave_kmin_s = __builtin_amdgcn_readfirstlane(wave_kmin);
+  };
+  wave_frontier();
 
   // kv_end >= 1 always (lq >= 1, off >= 0): unconditional, with an explicit vmcnt(0) — hipcc's waitcnt pass then KNOWS
   // the Q fragment loads have landed before the loop (with a conditional prologue it assumes they may be pending at the
@@ -306,9 +337,6 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   stage_write(0);
   __syncthreads();
 
-  // wave-uniform copies on the scalar side (scalar branches instead of exec masks)
-  const int wave_kmax_s = __builtin_amdgcn_readfirstlane(wave_kmax);
-  const int wave_kmin_s = __builtin_amdgcn_readfirstlane(wave_kmin);
 
   // ---- S^T tile: 2 key blocks x 32 keys; lane = query column ---------------------------------
   auto qk = [&](f32x16_t (&sacc)[2], const unsigned char* k_lds) {
@@ -404,6 +432,24 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   // One tile step, with the LDS buffer a COMPILE-TIME constant (the loop below is unrolled by the two buffers): every
   // ds_read / ds_write address is then a loop-invariant lane offset + an immediate, instead of ~25 VALU adds per tile
   // re-basing them on the buffer of the moment.
+  // PERSIST: the item after this one (has_next) — coordinates derived from the register-resident tile list, no memory
+  // access — so that its Q rows and first K/V tile can be requested during this item's LAST tile.
+  bool has_next = false;
+  int n_seq = 0, n_qblk = 0, n_q0 = 0, n_lq = 1, n_k0 = 0, n_lk = 1, n_head = 0, round = 0;
+  auto find_next = [&]() {
+    if constexpr (PERSIST) {
+      ++round;
+      // snake over the longest-first list: even rounds forwards, odd rounds backwards, so that a workgroup's items add up
+      // to the same work whichever slot it starts from (plain strides would give slot 0 the longest item of EVERY round)
+      const int nb = (int)gridDim.x;
+      const int b = (round & 1) ? (round + 1) * nb - 1 - (int)blockIdx.x : round * nb + (int)blockIdx.x;
+      int rank;
+      xcd_decode(b, n_head, rank);
+      n_head = __builtin_amdgcn_readfirstlane(n_head);
+      has_next = rank < total;       // ranks grow with the block id: the first invalid one ends the walk
+      if (has_next) reg_locate(rank, n_seq, n_qblk, n_q0, n_lq, n_k0, n_lk);
+    }
+  };
   auto tile_step = [&](auto buf_c, const int kt) {
     constexpr int buf = decltype(buf_c)::value;
     const bool more = kt + kKBlk < kv_end;
@@ -418,15 +464,38 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     if (active) qk(sacc, k_lds);
     __builtin_amdgcn_sched_barrier(0);
     if (more) stage_load(kt + kKBlk);
+    if constexpr (PERSIST) {
+      // last tile of the item: the next item's first K/V tile is requested now and lands under this tile's softmax / P.V
+      if (!more && has_next) stage_load_of(n_seq, n_head / (hq / hkv), n_k0, n_lk, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (active) softmax_pv(sacc, wave_kmin_s, kt, v_lds);
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PERSIST) {
+      // ... and its Q rows here (the Q fragments are dead since this tile's QK^T): they land under the barrier and the
+      // item's epilogue. (Requested together with the K/V tile, before the softmax, the kernel needs 20 more registers
+      // and the packed-K/V instantiation spills: 256 + 23 against 245.)
+      if (!more && has_next) load_q(n_q0, n_lq, n_qblk, n_head);
+    }
     if (more) stage_write(buf ^ 1);     // the other buffer was last read one barrier ago
+    if constexpr (PERSIST) {
+      // the next item's first tile always goes to buffer 0. After a last tile in buffer 1 that is the ordinary
+      // "other buffer" write; after one in buffer 0 the write has to wait for the barrier (buffer 0 is being read).
+      if (!more && has_next && buf == 1) stage_write(0);
+    }
     __syncthreads();
+    if constexpr (PERSIST) {
+      if (!more && has_next && buf == 0) {
+        stage_write(0);
+        __syncthreads();
+      }
+    }
   };
   // (Tried on top of this and dropped: a two-score-tile pipeline — QK^T of tile t+1 beside the softmax of tile t,
   // cdna_hip_programming.md T15 — with the interleave pinned block by block: 253-255 registers, 4-5 % SLOWER at
   // 1 x 16,384 than this loop; the rolled loop, 1-3 % slower. profiles/r03_prefill_ab_var{0,1,2}.json.)
+  for (;;) {       // one iteration per item (exactly one without PERSIST)
+  find_next();
   for (int kt = 0; kt < kv_end; kt += 2 * kKBlk) {
     tile_step(std::integral_constant<int, 0>{}, kt);
     if (kt + kKBlk >= kv_end) break;
@@ -462,6 +531,23 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
       // lanes 0-31: [own group 2rp | upper half's group 2rp] = d db*32 + 16 rp + 0..7; lanes 32-63: the next 8
       if (q_valid) *reinterpret_cast<u32x4_t*>(op + db * 32 + 16 * rp) = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
     }
+  if constexpr (!PERSIST) {
+    break;
+  } else {
+    if (!has_next) break;
+    // ---- switch to the next item: its first tile sits in LDS buffer 0, its Q fragments are in flight or landed ------
+    seq = n_seq; qblk = n_qblk; q0 = n_q0; lq = n_lq; k0 = n_k0; lk = n_lk; head = n_head;
+    item_geometry();
+    kmax_vis = qi_c + off;
+    wave_frontier();
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+    m_run = kNegBig;
+    l_run = 0.f;
+  }
+  }   // items
 }
 
 }  // namespace
@@ -508,8 +594,10 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // numbering is +3...11 % on bench-like / ragged batches of 100-1024-token prompts, +-1 % on the long shapes, -2...4 %
   // on launches of > 64 very short sequences => ON by default for 4-wave launches of <= 64 sequences; NVL_PREFILL_XCD=0|1
   // forces it off / on for every launch.
-  static int xcd_env = -2, waves = -1;
+  static int xcd_env = -2, waves = -1, persist_env = 0;
   if (xcd_env == -2) {
+    const char* pe = getenv("NVL_PREFILL_PERSIST");
+    persist_env = (pe && pe[0] == '1') ? 1 : 0;                  // (opt-in until measured: see the kernel's PERSIST note)
     const char* e = getenv("NVL_PREFILL_XCD");
     xcd_env = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
     const char* w = getenv("NVL_PREFILL_WAVES");
@@ -519,11 +607,15 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   const bool eight_ok = (num_q_heads / num_kv_heads) % 2 == 0;
   const int xcd_map = xcd_env >= 0 ? xcd_env : ((want == 4 || !eight_ok) && num_seqs <= 64 ? 1 : 0);
   const bool eight = want == 8 && !xcd_map && eight_ok;
+  // persistent walk over the item list: 4-wave shape, XCD-aware numbering, tile list in registers (<= 64 sequences)
+  const bool persist = persist_env && xcd_map && !eight && num_seqs <= 64;
   dim3 grid((unsigned)(eight ? num_q_heads / 2 : num_q_heads), (unsigned)tiles);
   if (xcd_map) {
     const int64_t groups = tiles * num_kv_heads;
-    const int64_t blocks = ((groups + 7) / 8) * 8 * (num_q_heads / num_kv_heads);
+    int64_t blocks = ((groups + 7) / 8) * 8 * (num_q_heads / num_kv_heads);
     NVL_REQUIRE(blocks < (1ll << 31), "nvl_attn_prefill_varlen: too many workgroups (%lld)", (long long)blocks);
+    // (persist: two resident workgroups per CU walk the list; 2 x CUs is a multiple of 8 G for every group size)
+    if (persist && blocks > 2 * (int64_t)nvl_device_cu_count()) blocks = 2 * (int64_t)nvl_device_cu_count();
     grid = dim3((unsigned)blocks, 1);
   } else {
     NVL_REQUIRE(tiles <= 65535, "nvl_attn_prefill_varlen: too many query tiles (%lld)", (long long)tiles);
@@ -537,25 +629,35 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
 #define NVL_PF_ATTR(P, K8, NWV)                                                                            \
     (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<P, K8, NWV>),                  \
                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess)
+#define NVL_PF_ATTR_P(P, K8)                                                                               \
+    (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<P, K8, 4, true>),              \
+                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess)
     if (NVL_PF_ATTR(true, false, 4) || NVL_PF_ATTR(true, true, 4) || NVL_PF_ATTR(false, false, 4) ||
-        NVL_PF_ATTR(true, false, 8) || NVL_PF_ATTR(true, true, 8) || NVL_PF_ATTR(false, false, 8)) {
+        NVL_PF_ATTR(true, false, 8) || NVL_PF_ATTR(true, true, 8) || NVL_PF_ATTR(false, false, 8) ||
+        NVL_PF_ATTR_P(true, false) || NVL_PF_ATTR_P(true, true) || NVL_PF_ATTR_P(false, false)) {
       nvl_set_error("nvl_attn_prefill_varlen: cannot reserve %zu B of LDS", cap);
       return NVL_ELAUNCH;
     }
 #undef NVL_PF_ATTR
+#undef NVL_PF_ATTR_P
     lds_cap = cap;
   }
 #define NVL_PF_LAUNCH(P, K8, NWV)                                                                                      \
   hipLaunchKernelGGL((prefill_attn_kernel<P, K8, NWV>), grid, dim3(NWV * 64), lds, s, (const bf16_t*)q,                 \
                      (const bf16_t*)k, (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k,        \
                      block_tables, bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map, lse)
+#define NVL_PF_LAUNCH_P(P, K8)                                                                                         \
+  hipLaunchKernelGGL((prefill_attn_kernel<P, K8, 4, true>), grid, dim3(4 * 64), lds, s, (const bf16_t*)q,               \
+                     (const bf16_t*)k, (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k,        \
+                     block_tables, bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map, lse)
   if (paged && kv_dtype == NVL_KV_FP8) {
-    if (eight) NVL_PF_LAUNCH(true, true, 8); else NVL_PF_LAUNCH(true, true, 4);
+    if (persist) NVL_PF_LAUNCH_P(true, true); else if (eight) NVL_PF_LAUNCH(true, true, 8); else NVL_PF_LAUNCH(true, true, 4);
   } else if (paged) {
-    if (eight) NVL_PF_LAUNCH(true, false, 8); else NVL_PF_LAUNCH(true, false, 4);
+    if (persist) NVL_PF_LAUNCH_P(true, false); else if (eight) NVL_PF_LAUNCH(true, false, 8); else NVL_PF_LAUNCH(true, false, 4);
   } else {
-    if (eight) NVL_PF_LAUNCH(false, false, 8); else NVL_PF_LAUNCH(false, false, 4);
+    if (persist) NVL_PF_LAUNCH_P(false, false); else if (eight) NVL_PF_LAUNCH(false, false, 8); else NVL_PF_LAUNCH(false, false, 4);
   }
 #undef NVL_PF_LAUNCH
+#undef NVL_PF_LAUNCH_P
   return nvl_check_launch("nvl_attn_prefill_varlen");
 }

@@ -1,0 +1,19 @@
+#!/bin/bash
+# round 4, call 5: persistent prefill attention (NVL_PREFILL_PERSIST=1) — the prefill tests with it on, A/B on the
+# micro-benchmark shapes, and the bench's own prefill batches through bench.py --no-cpu-baseline (roofline_prefill)
+set -u
+OUT=gpurun_out/r04e; mkdir -p $OUT; export TMPDIR=/tmp
+NVL_PREFILL_PERSIST=1 timeout 900 python -m pytest tests/test_kernels_gpu.py -m gpu -q -rf -k "prefill" > $OUT/pytest_prefill_persist.log 2>&1; echo "prefill tests (persist) rc=$?"; tail -3 $OUT/pytest_prefill_persist.log
+NVL_PREFILL_PERSIST=1 timeout 600 python -m pytest tests/test_e2e_gpu.py -m gpu -q -rf -k "tiny_model_greedy or chunked or other_head" > $OUT/pytest_e2e_persist.log 2>&1; echo "e2e (persist) rc=$?"; tail -2 $OUT/pytest_e2e_persist.log
+for p in 0 1 0 1; do
+  NVL_PREFILL_PERSIST=$p timeout 300 python tools/prefill_bench.py > $OUT/prefill_persist${p}_$RANDOM.json 2> /dev/null
+done
+python - <<'P'
+import json,glob
+from collections import defaultdict
+r=defaultdict(lambda: defaultdict(list))
+for f in sorted(glob.glob('gpurun_out/r04e/prefill_persist*_*.json')):
+    p=f.split('persist')[1][0]
+    for c in json.load(open(f))['cases']: r[c['name']][p].append(c['TFLOPs'])
+for n,v in r.items(): print(n.ljust(40),'off',v['0'],'on',v['1'])
+P
