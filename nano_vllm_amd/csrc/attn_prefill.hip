@@ -56,7 +56,13 @@ constexpr int kTileBytes = kKBlk * (kKRowB + kVRowB);   // one K + V tile pair i
 //         balance) — and, during the LAST key tile of an item, already requests the next item's Q rows and first K/V
 //         tile: the per-item fixed cost of a short sequence's workgroup (dispatch, the cu_seqlens round trip, the Q and
 //         first-tile round trip, the store tail — about half of its ~25 us at the bench's prompt lengths) shrinks to the
-//         epilogue arithmetic. The tile list stays in registers for the whole launch.
+//         epilogue arithmetic. The tile list stays in registers for the whole launch. Bit-identical to the plain launch
+//         (same arithmetic per item). MEASURED (profiles/r04_prefill_persist_ab.json): +13 % on batches of EQUAL-length
+//         sequences (16 x 1024: 571 -> 644 TF), but -8 ... -12 % on the bench's ragged batches — with items of 1 to 17
+//         tiles the hardware's dynamic dispatch balances better than the static snake, and the two q-heads of a kv group
+//         drift apart in time and stop sharing their K/V tiles through the L2 — so the launcher takes this path only
+//         for uniform batches (total_q == num_seqs x max_seqlen_q). A "group walk" (one workgroup per (tile, kv-head)
+//         group, its G heads back to back) was measured as well and is slower everywhere (16 x 1024: 447 TF): removed.
 template <bool PAGED, bool KV8, int NW, bool PERSIST = false>
 __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_tok_stride,
@@ -594,10 +600,12 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // numbering is +3...11 % on bench-like / ragged batches of 100-1024-token prompts, +-1 % on the long shapes, -2...4 %
   // on launches of > 64 very short sequences => ON by default for 4-wave launches of <= 64 sequences; NVL_PREFILL_XCD=0|1
   // forces it off / on for every launch.
-  static int xcd_env = -2, waves = -1, persist_env = 0;
+  static int xcd_env = -2, waves = -1;
+  // persistent walk: NVL_PREFILL_PERSIST=0|1 forces it off / on (read at every call: tests compare both in one
+  // process); unset = on for batches of equal-length sequences, where it measured +13 %
+  const char* pe = getenv("NVL_PREFILL_PERSIST");
+  const int persist_env = (pe && (pe[0] == '0' || pe[0] == '1')) ? pe[0] - '0' : -1;
   if (xcd_env == -2) {
-    const char* pe = getenv("NVL_PREFILL_PERSIST");
-    persist_env = (pe && pe[0] == '1') ? 1 : 0;                  // (opt-in until measured: see the kernel's PERSIST note)
     const char* e = getenv("NVL_PREFILL_XCD");
     xcd_env = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
     const char* w = getenv("NVL_PREFILL_WAVES");
@@ -608,7 +616,8 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   const int xcd_map = xcd_env >= 0 ? xcd_env : ((want == 4 || !eight_ok) && num_seqs <= 64 ? 1 : 0);
   const bool eight = want == 8 && !xcd_map && eight_ok;
   // persistent walk over the item list: 4-wave shape, XCD-aware numbering, tile list in registers (<= 64 sequences)
-  const bool persist = persist_env && xcd_map && !eight && num_seqs <= 64;
+  const bool uniform = total_q == (int64_t)num_seqs * max_seqlen_q;
+  const bool persist = (persist_env >= 0 ? persist_env == 1 : uniform) && xcd_map && !eight && num_seqs <= 64;
   dim3 grid((unsigned)(eight ? num_q_heads / 2 : num_q_heads), (unsigned)tiles);
   if (xcd_map) {
     const int64_t groups = tiles * num_kv_heads;

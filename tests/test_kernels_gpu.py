@@ -603,6 +603,45 @@ def test_prefill_paged_prefix(ops, hq, hkv, lq_lk):
     assert float((lse.cpu() - lse_ref).abs().max()) <= 2e-3
 
 
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1), (32, 8)])
+@pytest.mark.parametrize("lens", [[1024] * 16, [561] * 29, [100, 1000, 33, 257, 640, 129, 128, 1], [300] * 64])
+def test_prefill_persistent_walk_is_bit_identical_to_the_plain_launch(ops, hq, hkv, lens, monkeypatch):
+    """The persistent form of the prefill kernel (workgroups walk the longest-first item list in a snake and prefetch the
+    next item's first K/V tile and Q rows; taken by itself for equal-length batches, NVL_PREFILL_PERSIST=0|1 forces it)
+    does the same arithmetic per item: output and LSE must equal the plain launch bit for bit — packed K/V and, for the
+    ragged case, the paged cache (chunk continuation) as well — and both must match the oracle."""
+    gen = g(60 + len(lens))
+    n = sum(lens)
+    q = torch.randn(n, hq, 128, generator=gen).to(BF16)
+    k = torch.randn(n, hkv, 128, generator=gen).to(BF16)
+    v = torch.randn(n, hkv, 128, generator=gen).to(BF16)
+    cu = _cu(lens)
+    scale = 128 ** -0.5
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NVL_PREFILL_PERSIST", mode)
+        lse = torch.zeros(n, hq, dtype=torch.float32, device="cuda")
+        o = ops.attn_prefill_varlen(dev(q), dev(k), dev(v), dev(cu), dev(cu), max(lens), scale, lse=lse)
+        outs[mode] = (o.cpu(), lse.cpu())
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    if n <= 4096:
+        o_ref = ref.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, scale)
+        assert float((outs["1"][0].float() - o_ref.float()).abs().max()) <= 2e-2 * float(o_ref.float().abs().max()) + 1e-3
+    if len(lens) == 8:                                   # paged: queries continue a cached prefix
+        lqs = [max(1, l // 3) for l in lens]
+        kc, vc, bt = _paged_setup(lens, hkv, 256, seed=61)
+        qp = torch.randn(sum(lqs), hq, 128, generator=gen).to(BF16)
+        cuq = _cu(lqs)
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("NVL_PREFILL_PERSIST", mode)
+            res[mode] = ops.attn_prefill_varlen(dev(qp), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(cuq),
+                                                dev(cu), max(lqs), scale, block_tables=dev(bt)).cpu()
+        assert torch.equal(res["0"], res["1"])
+        o_ref = ref.flash_attn_varlen_func(qp, kc, vc, max(lqs), cuq, max(lens), cu, scale, True, bt)
+        assert float((res["1"].float() - o_ref.float()).abs().max()) <= 2e-2 * float(o_ref.float().abs().max()) + 1e-3
+
+
 def test_prefill_softmax_rescale_branch(ops):
     """Force a large running-max jump at a late tile (guide §5.4 rule 26): spike one key."""
     hq = hkv = 8
