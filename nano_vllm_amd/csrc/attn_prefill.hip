@@ -619,7 +619,7 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // by itself only where the static snake is provably balanced: equal-length sequences AND an even number of full
   // rounds of 2 x CUs workgroups (16 x 1024 tokens on 16 heads = 2048 items = 4 rounds: +13 %; 29 x 561 = 4.5 rounds
   // measured -4 ... +1 %: the odd half round lands on the workgroups that already hold the longest items)
-  const int64_t all_items = (((tiles * num_kv_heads) + 7) / 8) * 8 * (num_q_heads / num_kv_heads);
+  const int64_t all_items = (int64_t)num_seqs * ((max_seqlen_q + kQBlk - 1) / kQBlk) * num_q_heads;   // exact when uniform
   const int64_t per_round = 2 * (int64_t)nvl_device_cu_count();
   const bool uniform = total_q == (int64_t)num_seqs * max_seqlen_q && total_q % kQBlk == 0 &&
                        all_items >= 2 * per_round && all_items % (2 * per_round) == 0;
