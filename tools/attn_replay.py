@@ -114,7 +114,9 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
             layers()
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # (inference mode: inside bench.py the engine has captured its own graphs under it, and torch's capture
+            #  bookkeeping then touches generator state that only inference mode may update)
+            with torch.inference_mode(), torch.cuda.graph(g):
                 layers()
             runner = g.replay
         for _ in range(reps):                       # keep the last rep (caches are 100s of MB: nothing stays warm)
