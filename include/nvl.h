@@ -206,6 +206,10 @@ int nvl_qknorm_rope_kvstore(const void* qkv, int64_t qkv_tok_stride,
  *   nvl_decode_plan for the SAME (context_lens, batch, Hq, Hkv, max_context);
  *   with it the kernel skips its own prefix scan / search (the plan is the same
  *   for every layer of a decode step: make it once, pass it to every layer).
+ *   The library remembers the (batch, Hkv, max_context) each plan buffer was
+ *   built for and REFUSES (NVL_EINVAL) a launch whose geometry differs, or a
+ *   buffer nvl_decode_plan never filled on this device: the kernel indexes the
+ *   plan's per-wave records by wave id.
  * lse (optional, may be NULL): fp32 [batch, Hq] log-sum-exp of the scaled
  *   scores, natural log — flash-attn's `softmax_lse` (return_softmax_lse=True);
  *   -inf for padded rows. */
