@@ -454,6 +454,20 @@ double wide_cost(int64_t m, int n, int k, int mode, const WidePlan& p) {
   return t;
 }
 
+// Measured-best decompositions at 193-256 rows where the model above mis-ranks them (round-4 sweeps at 208 / 256 rows,
+// profiles/r04_gemm_wide_sweep_m208_m256.jsonl; the model was fitted at 144 rows and under-estimates the 13-16-row-tile
+// form by 7-35 %, and a blanket penalty on that form sends other shapes to worse plans): the deep-K slab projections are
+// fastest as TWO paired row groups of <= 9 tiles with two column tiles per wave. us at 256 (208) rows, planner -> tuned:
+//   Qwen3-8B  down [4096, 12288]  50.2 (49.4) -> 44.5 (36.3)      Qwen3-32B down [5120, 25600]  130.4 -> 111.7
+//   Qwen3-32B qkv  [10240, 5120]  48.2 -> 45.6                     Qwen3-8B  o    [4096, 4096] at 208 rows  15.8 -> 14.6
+struct TunedPlan { int n, k, mode, mtiles_lo, mtiles_hi, nt, nw, split; };
+constexpr TunedPlan kTuned[] = {
+    {4096, 12288, EPI_PARTIAL, 13, 16, 2, 4, 4},
+    {5120, 25600, EPI_PARTIAL, 13, 16, 2, 4, 8},
+    {10240, 5120, EPI_BF16, 13, 16, 2, 3, 1},
+    {4096, 4096, EPI_PARTIAL, 13, 13, 2, 4, 4},
+};
+
 bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
   if (m < 1 || m > 1024 || n < 16 || k < kBK || k % kBK) return false;
   if (m * (int64_t)k >= (1ll << 31) || (int64_t)n * k >= (1ll << 40)) return false;   // 32-bit x element offsets in the loader
@@ -461,8 +475,13 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
   const int out_cols = mode == EPI_SILU ? n / 2 : n;
   const int mtiles = (int)((m + 15) / 16);
   const int force_bk = env_int("NVL_WIDE_BK", 0) == 128 ? 128 : 0;
-  const int force_nt = env_int("NVL_WIDE_NT", 0), force_nw = env_int("NVL_WIDE_NW", 0);
-  const int force_split = env_int("NVL_WIDE_SPLIT", 0);
+  int force_nt = env_int("NVL_WIDE_NT", 0), force_nw = env_int("NVL_WIDE_NW", 0);
+  int force_split = env_int("NVL_WIDE_SPLIT", 0);
+  if (!force_nt && !force_nw && !force_split && env_int("NVL_WIDE_TUNED", 1))
+    for (const TunedPlan& t : kTuned)
+      if (t.n == n && t.k == k && t.mode == mode && mtiles >= t.mtiles_lo && mtiles <= t.mtiles_hi) {
+        force_nt = t.nt; force_nw = t.nw; force_split = t.split;
+      }
   double best_t = 1e30;
   for (int nt : {2, 1}) {
     if (force_nt && nt != force_nt) continue;
