@@ -132,6 +132,12 @@ __device__ __forceinline__ float wave_allreduce_max(float v) {
   return v;
 }
 
+// Natural log on the transcendental unit for arguments that are never denormal (the sampler's uniforms are >= 2^-25,
+// its exponentials >= 1e-10): v_log_f32 (log2) x ln 2 — what hipcc's __logf computes, minus its denormal range fix-up
+// (a compare, two selects, a scale and a subtraction per call, ~6 VALU), which never fires here. Bit-identical to
+// __logf on normal inputs.
+__device__ __forceinline__ float log_normal_f32(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
 // ---- Philox4x32-10 (host + device, identical) -------------------------------------
 struct Philox4 {
   uint32_t v[4];

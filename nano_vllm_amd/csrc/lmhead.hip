@@ -210,9 +210,9 @@ __global__ __launch_bounds__(kNW * 64) void lmhead_sample_kernel(
                                           (uint32_t)(off >> 24), k0, k1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float e = -__logf(u01_bits(rnd.v[r]));
+          float e = -log_normal_f32(u01_bits(rnd.v[r]));
           e = e < 1e-10f ? 1e-10f : e;
-          key[r] = greedy ? v[r] : v[r] * invT - __logf(e);
+          key[r] = greedy ? v[r] : v[r] * invT - log_normal_f32(e);
         }
       }
 #pragma unroll

@@ -23,7 +23,7 @@ __host__ __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >>
 
 __host__ __device__ __forceinline__ float exp1_from_bits(uint32_t x) {
 #ifdef __HIP_DEVICE_COMPILE__
-  const float e = -__logf(u01(x));
+  const float e = -log_normal_f32(u01(x));
 #else
   const float e = -logf(u01(x));
 #endif
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void sample_partial_kernel(const bf16_t* __res
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const uint32_t bits = i < 4 ? r0.v[i] : r1.v[i - 4];
-        key[i] = f[i] * invT - __logf(exp1_from_bits(bits));
+        key[i] = f[i] * invT - log_normal_f32(exp1_from_bits(bits));
       }
     }
 #pragma unroll
