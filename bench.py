@@ -263,7 +263,6 @@ def base_result(args, tp, world_engines, n_gpus, elapsed, total_out, llm, parall
                    "hipgraph": not llm.model_runner.enforce_eager, "kv_blocks": llm.config.num_kvcache_blocks,
                    "packed_weight_bytes": getattr(llm.model_runner, "packed_weight_bytes", None),
                    "projections_left_row_major_for_lack_of_budget": getattr(llm.model_runner, "packed_weight_skipped", None),
-                   "hipblaslt_prefill_tuning_table": bool(getattr(llm.model_runner, "blas_tuning", None)),
                    "output_tokens_per_step": total_out},
     }
 

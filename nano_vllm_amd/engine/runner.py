@@ -272,7 +272,6 @@ class ModelRunner:
             # tile-packed copies of the deep-K projections for the decode GEMM (before the KV pool is sized from what
             # is left: a second copy of those weights is the price of a 4x cheaper weight stream per CU)
             self.packed_weight_bytes, self.packed_weight_skipped = self._pack_weights()
-            self.blas_tuning = self._load_blas_tuning()
             self.sampler = Sampler(seed=config.seed, max_rows=config.max_num_seqs)
             # decode micro-batching (see _forward_decode): second chain's stream, sampler and workspace
             self.microbatches = int(os.environ.get("NVL_MICROBATCHES", "1")) if self.world_size == 1 else 1
@@ -299,29 +298,6 @@ class ModelRunner:
                 dist.barrier()
                 self.chan = _Channel(name, payload, self.world_size, create=False)
                 self.loop()
-
-    @staticmethod
-    def _load_blas_tuning() -> str | None:
-        """Prefill-sized projections run on the library GEMM (hipBLASLt through F.linear). Its heuristic pick is 20-25 %
-        off its best solution on the Qwen3-32B projections at 16,000 rows (profiles/r04_blas_prefill_probe.json), so the
-        package ships the result table of an OFFLINE search (tools/blas_tune_prefill.py, torch TunableOp) and the engine
-        loads it: shapes in the table take the recorded solution, every other shape the library's default; no search ever
-        runs in the engine. The table is ignored by torch when it was made with another ROCm / hipBLASLt / GPU (its header
-        is validated). NVL_BLAS_TUNED=0 disables it. Returns the file loaded, or None."""
-        if os.environ.get("NVL_BLAS_TUNED", "1") == "0":
-            return None
-        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tuned",
-                            "hipblaslt_prefill_gfx950.csv")
-        if not os.path.exists(path):
-            return None
-        try:
-            import torch.cuda.tunable as tunable
-            tunable.enable(True)
-            tunable.tuning_enable(False)
-            tunable.set_filename(os.path.join(os.environ.get("TMPDIR", "/tmp"), f"nvl_tunableop_{os.getpid()}.csv"))
-            return path if tunable.read_file(path) else None
-        except Exception:           # noqa: BLE001 — an optional speed-up must never stop the engine
-            return None
 
     def _pack_weights(self) -> tuple[int, int]:
         """Tile-packed second copies of the decode GEMMs' weights, under a BUDGET: they are allocated before the KV
