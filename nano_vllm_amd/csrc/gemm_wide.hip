@@ -454,16 +454,25 @@ double wide_cost(int64_t m, int n, int k, int mode, const WidePlan& p) {
   return t;
 }
 
-// Measured-best decompositions at 193-256 rows where the model above mis-ranks them (round-4 sweeps at 208 / 256 rows,
-// profiles/r04_gemm_wide_sweep_m208_m256.jsonl; the model was fitted at 144 rows and under-estimates the 13-16-row-tile
-// form by 7-35 %, and a blanket penalty on that form sends other shapes to worse plans): the deep-K slab projections are
-// fastest as TWO paired row groups of <= 9 tiles with two column tiles per wave. us at 256 (208) rows, planner -> tuned:
-//   Qwen3-8B  down [4096, 12288]  50.2 (49.4) -> 44.5 (36.3)      Qwen3-32B down [5120, 25600]  130.4 -> 111.7
-//   Qwen3-32B qkv  [10240, 5120]  48.2 -> 45.6                     Qwen3-8B  o    [4096, 4096] at 208 rows  15.8 -> 14.6
+// Measured-best decompositions where the model above mis-ranks them (round-4 sweeps of every (NT, NW, split) plan at 32 ...
+// 256 rows, profiles/r04_gemm_wide_sweep_*.jsonl). The model was fitted at 144 rows on the round-3 kernel; it
+// under-estimates the 13-16-row-tile form by 7-35 % (a blanket penalty on that form sends other shapes to worse plans) and,
+// for the deep-K slab projections, prefers four thin waves x one column tile where two column tiles per wave (half the x
+// fragment reads per MFMA) with a deeper K split are 10-17 % faster. us, planner -> tuned:
+//   Qwen3-8B  down [4096, 12288]  64-144 rows: 24.0 / 32.7 / 33.2 -> 21.9 / 27.3 / 28.1 (at 64 / 131 / 144)
+//                                 208 / 256 rows: 49.4 / 50.2 -> 37.4 / 45.2 (two paired row groups)
+//   Qwen3-32B down [5120, 25600]  96 rows 72.7 -> 66.0;  112-144 rows: 80.5 / 87.8 / 93.0 -> 69.3 / 74.9 / 78.2;  256: 130 -> 112.5
+//   Qwen3-32B qkv  [10240, 5120]  32-144 rows: 25.0 / 32.9 / 39.2 / 39.8 -> 23.2 / 29.5 / 36.3 / 38.0;  256: 47.7 -> 45.6
+//   Qwen3-8B  o    [4096, 4096]   208 rows: 15.8 -> 14.6
+// NVL_WIDE_TUNED=0 = the model's picks everywhere (A/B).
 struct TunedPlan { int n, k, mode, mtiles_lo, mtiles_hi, nt, nw, split; };
 constexpr TunedPlan kTuned[] = {
+    {4096, 12288, EPI_PARTIAL, 4, 9, 2, 4, 8},
     {4096, 12288, EPI_PARTIAL, 13, 16, 2, 4, 4},
+    {5120, 25600, EPI_PARTIAL, 6, 6, 2, 4, 4},
+    {5120, 25600, EPI_PARTIAL, 7, 9, 2, 3, 8},
     {5120, 25600, EPI_PARTIAL, 13, 16, 2, 4, 8},
+    {10240, 5120, EPI_BF16, 2, 9, 2, 3, 2},
     {10240, 5120, EPI_BF16, 13, 16, 2, 3, 1},
     {4096, 4096, EPI_PARTIAL, 13, 13, 2, 4, 4},
 };
