@@ -15,6 +15,13 @@ third-party packages that are NOT under /root/reference:
   * torch.compile / inductor (torch>=2.4.0)       -> rounding points of the compiled graphs
   * xxhash (unpinned, pyproject.toml:19)          -> imported directly (it is installed)
 
+One file restates the PRODUCT, not the reference: `oracle/philox.py` is an independent numpy restatement of the sampler's
+counter-based draw (Philox4x32-10 keyed by seed / request ordinal / position / column), pinned to the published
+Random123 known-answer vectors and to the library's own host replay. The reference's draw (torch's generator consumed
+in batch order, sampler.py:11) is not reproducible even between the reference's eager and compiled forms; with the
+product's draw restated, `oracle/judge.py` can judge sampled tokens EXACTLY on the oracle's logits
+(argmax of l/T - log E) instead of only distributionally.
+
 Pinning status: the reference ships no tests and no golden vectors, so parity
 is pinned by outputs of the reference ITSELF, produced in the build container by importing
 /root/reference with a `flash_attn` stub (oracle/ref_import.py, oracle/make_golden.py) and
