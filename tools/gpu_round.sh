@@ -129,6 +129,19 @@ import json; d=json.load(open('$OUT/bench_full.json')); print(round(d['value']),
 pmcprefillfetch)
   (cd /tmp && rm -rf /tmp/pmc_pf_fetch && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_pf_fetch -o pf -- python $REPO/tools/prefill_bench.py > $OUT/prefill_under_pmc_fetch.json 2> $OUT/prefill_pmc_fetch.err; echo "pmcprefillfetch rc=$?")
   f=$(find /tmp/pmc_pf_fetch -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_prefill_fetch.py $f $OUT/prefill_pmc_fetch_summary.json | tail -40;;
+final)
+  # the whole validation of a tree: GPU suite, smoke, the bench line, rocprofv3 kernel stats of the bench
+  timeout 1500 python -m pytest tests -m gpu -q -rf --durations=6 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?"
+  grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_gpu.log | cut -c1-300 | tail -20
+  timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('__SMOKE_OK__')" > $OUT/smoke.log 2>&1; echo "smoke rc=$?"; grep -v amdgpu.ids $OUT/smoke.log | tail -2
+  bash tools/gpu_round.sh $TAG benchfull benchprof;;
+widesweep)
+  # every (NT, NW, split) plan of the wide decode GEMM at the row counts in SWEEP_M on the shapes in SWEEP_SHAPES
+  timeout 900 python tools/gemm_wide_sweep.py ${SWEEP_M:-131 144 256} > $OUT/gemm_wide_sweep.jsonl 2> $OUT/gemm_wide_sweep.err; echo "sweep rc=$?";;
+skinnysweep)
+  timeout 600 python tools/gemm_skinny_sweep.py ${SWEEP_M:-64 131 208} > $OUT/skinny_sweep.jsonl 2> $OUT/skinny_sweep.err; echo "skinny sweep rc=$?";;
+persistab)
+  for p in 0 1 0 1; do NVL_PREFILL_PERSIST=$p timeout 300 python tools/prefill_bench.py > $OUT/prefill_persist${p}_$RANDOM.json 2> /dev/null; done;;
 prefillbench)
   timeout 600 python tools/prefill_bench.py > $OUT/prefill_bench.json 2> $OUT/prefill_bench.err; echo "prefill rc=$?"; cat $OUT/prefill_bench.json;;
 *) echo "unknown step $w";;
