@@ -284,6 +284,8 @@ def run_tp_external(args, torch, dist, rank, world, tp):
     result = base_result(args, tp, 1, world, elapsed, total_out, llm,
                          f"tp{tp} (one engine, tensor-parallel over {tp} GPUs: xGMI P2P all-reduce "
                          f"{'on' if llm.model_runner.p2p else 'OFF (process-group fallback)'})")
+    from nano_vllm_amd import tp as tp_mod
+    result["config"]["p2p_handoff"] = tp_mod.handoff_report()
     try:
         llm.exit()
         result["config"]["p2p_status"] = "ok" if result["config"]["parallelism"].find("all-reduce on") >= 0 else "n/a"
