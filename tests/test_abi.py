@@ -108,6 +108,33 @@ def test_linear_wide_plan_covers_the_model_shapes_on_the_host():
     assert lib.nvl_add_rmsnorm_splitk(16, 0, 16, 16, 16, 4, 1024, 1e-6, None) == -1 and b"splits" in lib.nvl_last_error()
 
 
+def test_wide_plan_tuned_entries_resolve_on_the_host():
+    """The measured-best decompositions of gemm_wide.hip (kTuned) are plain data: each must resolve to a plan whose K
+    split is the recorded one for every row count of its range, the neighbouring row counts must keep the model's pick,
+    and NVL_WIDE_TUNED=0 must switch the table off."""
+    import ctypes
+    from nano_vllm_amd import ops
+    lib = ops.load_library()
+    sp, ws = ctypes.c_int(0), ctypes.c_size_t(0)
+
+    def split(m, n, k, mode):
+        assert lib.nvl_linear_wide_plan(m, n, k, mode, ctypes.byref(sp), ctypes.byref(ws)) == 1
+        return sp.value
+
+    for n, k, mode, rows, want in ((4096, 12288, 2, (64, 96, 131, 144), 8), (4096, 12288, 2, (208, 256), 4),
+                                   (5120, 25600, 2, (96,), 4), (5120, 25600, 2, (112, 131, 144), 8),
+                                   (5120, 25600, 2, (208, 256), 8), (10240, 5120, 0, (32, 64, 131, 144), 2),
+                                   (10240, 5120, 0, (208, 256), 1), (4096, 4096, 2, (208,), 4)):
+        for m in rows:
+            assert split(m, n, k, mode) == want, (m, n, k, mode, sp.value)
+    assert split(48, 4096, 12288, 2) == 4 and split(160, 4096, 12288, 2) == 4      # outside the ranges: the model's picks
+    os.environ["NVL_WIDE_TUNED"] = "0"
+    try:
+        assert split(131, 4096, 12288, 2) == 4 and split(131, 10240, 5120, 0) == 1
+    finally:
+        del os.environ["NVL_WIDE_TUNED"]
+
+
 def test_no_product_import_of_the_oracle():
     """The product path must never route through the oracle (or any CPU fallback)."""
     bad = []

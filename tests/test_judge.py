@@ -169,3 +169,19 @@ def test_sampled_run_of_the_oracle_is_judged_exact_and_a_wrong_draw_is_caught(ti
     print(v.line("oracle sampled run judged by itself"))
     assert v.ok() and v.exact == v.rows == sum(max_tokens) and v.sampled_rows == 9 + 11
     assert not judge_run(cfg, w, prompts, max_tokens, rec, 16, temperatures=temps, seed=seed + 1, max_num_seqs=8).ok()
+
+
+def test_restated_draw_is_column_addressable():
+    """The draw is a function of the GLOBAL column: a vocabulary shard's exponentials (col0 > 0) are a slice of the full
+    row's — what makes the vocab-parallel race merge to the TP = 1 token — and different (ordinal, position) pairs give
+    different rows."""
+    import numpy as np
+    from oracle.philox import exponentials
+    full = exponentials(99, 7, 1234, 4096)
+    for col0, n in ((0, 512), (8, 1000), (2048, 2048), (4088, 8)):
+        assert np.array_equal(exponentials(99, 7, 1234, n, col0), full[col0:col0 + n])
+    assert not np.array_equal(exponentials(99, 8, 1234, 4096), full)
+    assert not np.array_equal(exponentials(99, 7, 1235, 4096), full)
+    assert not np.array_equal(exponentials(100, 7, 1234, 4096), full)
+    # E ~ Exp(1): mean and variance of 4096 draws
+    assert abs(float(full.mean()) - 1.0) < 0.08 and abs(float(full.var()) - 1.0) < 0.2
