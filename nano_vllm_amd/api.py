@@ -78,4 +78,4 @@ def model_geometry(hf_config, tp: int = 1) -> dict:
         head_dim=head_dim, inter=hf_config.intermediate_size // tp, vocab=hf_config.vocab_size,
         vocab_per_rank=hf_config.vocab_size // tp, eps=hf_config.rms_norm_eps, rope_theta=float(rope_theta),
         max_pos=hf_config.max_position_embeddings, tie=bool(getattr(hf_config, "tie_word_embeddings", False)),
-        qk_norm=not getattr(hf_config, "attention_bias", False), dtype=dtype)
+        qk_norm=not getattr(hf_config, "attention_bias", True), dtype=dtype)    # (default as models/qwen3.py:133)

@@ -275,25 +275,29 @@ bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
   // o_proj-like slab outputs (K <= 2048) from 9 row tiles on: THREE row groups x a 2-way K split (192 workgroups, two
   // slabs for the norm to sum) beat two groups x 4-way (256 workgroups, four slabs): 8.2 -> 7.7 us at 131 rows, 9.6 -> 9.2
   // at 208 (same sweep); deeper K (down_proj, 3072) has no single-pass 2-way split and stays as it was
-  if (mode == EPI_PARTIAL && nt == 2 && col_wgs < 1024 && mtiles >= 9 && k <= 2048 && k % (2 * kNW * 32) == 0) mgroups = 3;
+  // (only while three groups keep a group within the 16 instantiated row tiles; beyond 48 row tiles the ceil(mtiles / 16)
+  // groups of the general rule stand)
+  if (mode == EPI_PARTIAL && nt == 2 && col_wgs < 1024 && mtiles >= 9 && mtiles <= 48 && k <= 2048 && k % (2 * kNW * 32) == 0)
+    mgroups = 3;
   int split = 1;
   if (mode == EPI_PARTIAL) {                      // fill the chip: ~256 workgroups
     while (split < 8 && col_wgs * mgroups * split * 2 <= 256 && k % (split * 2 * kNW * 32) == 0) split *= 2;
   }
-  // A/B override for tools/gemm_skinny_sweep.py: NVL_SKINNY_PLAN="nt,mgroups,split" (0 = keep the rule's value)
-  if (const char* e = getenv("NVL_SKINNY_PLAN")) {
-    int f_nt = 0, f_mg = 0, f_sp = 0;
-    if (sscanf(e, "%d,%d,%d", &f_nt, &f_mg, &f_sp) >= 1) {
-      if (f_nt == 1 || f_nt == 2) {
-        if (mode == EPI_SILU && f_nt != 2) return false;
-        if (f_nt == 2 && mode != EPI_SILU && tiles % 2) return false;
-        nt = f_nt;
-      }
-      if (f_mg > 0) mgroups = f_mg;
-      if (f_sp > 0 && mode == EPI_PARTIAL) split = f_sp;
-      if (mgroups > mtiles) return false;
-    }
+  // A/B override for tools/gemm_skinny_sweep.py: NVL_SKINNY_PLAN="nt,mgroups,split" (0 = keep the rule's value). Read ONCE
+  // per process (this function is on the decode hot path, and a caller may have sized its slab scratch from an earlier
+  // answer); a forced value that breaks an invariant of the rule makes the shape "not covered" instead of a bad launch.
+  static const struct Forced { int nt = 0, mg = 0, sp = 0; Forced() { if (const char* e = getenv("NVL_SKINNY_PLAN")) sscanf(e, "%d,%d,%d", &nt, &mg, &sp); } } forced;
+  if (forced.nt == 1 || forced.nt == 2) {
+    if (mode == EPI_SILU && forced.nt != 2) return false;
+    if (forced.nt == 2 && mode != EPI_SILU && tiles % 2) return false;
+    nt = forced.nt;
   }
+  if (forced.mg > 0) mgroups = forced.mg;
+  if (forced.sp > 0 && mode == EPI_PARTIAL) {
+    if (forced.sp != 1 && forced.sp != 2 && forced.sp != 4 && forced.sp != 8) return false;
+    split = forced.sp;
+  }
+  if (mgroups > mtiles) return false;
   if (k % (split * kNW * 32)) return false;
   const int kw = k / (split * kNW * 32);          // 32-wide k blocks per wave
   int kb = 0;
@@ -307,6 +311,7 @@ bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
   p->nt = nt;
   p->mgroups = mgroups;
   p->mt = (mtiles + mgroups - 1) / mgroups;
+  if (p->mt > 16 || (mgroups - 1) * p->mt >= mtiles) return false;   // 16 row tiles are instantiated; no empty row group
   return true;
 }
 

@@ -72,7 +72,7 @@ class Qwen3DecoderLayer(nn.Module):
     def __init__(self, config, geo: dict):
         super().__init__()
         self.self_attn = Qwen3Attention(geo, config.num_attention_heads, config.num_key_value_heads,
-                                        qkv_bias=getattr(config, "attention_bias", False))
+                                        qkv_bias=getattr(config, "attention_bias", True))     # default as models/qwen3.py:133
         self.mlp = Qwen3MLP(config.hidden_size, config.intermediate_size, config.hidden_act)
         self.input_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(config.hidden_size, eps=config.rms_norm_eps)

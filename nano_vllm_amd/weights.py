@@ -41,6 +41,7 @@ QWEN3_SHAPES = {
     # heads, 1 kv head, intermediate 25600 / 8; with vocab_size 151936 / 8 also its embedding / lm_head shard): run as a
     # TP = 1 engine it does a rank's work minus the collectives — bench.py's `tp8_rank_shape` upper bound
     "qwen3-32b-tp8rank": (5120, 3200, 64, 8, 1, False),
+    "qwen3-32b-tp4rank": (5120, 6400, 64, 16, 2, False),     # ... and of tensor_parallel_size = 4 (BASELINE config 4)
 }
 
 

@@ -386,6 +386,76 @@ def test_bench_tp_extra_child_job_outcomes(monkeypatch):
     _json.dumps(r)
 
 
+def test_bench_tp_run_falls_back_to_the_process_group_and_never_reports_null():
+    """bench.py's tensor-parallel runs (round-4 review item 1d): a pass whose xGMI P2P collectives latched a spin timeout
+    is re-run with the process group's collectives on EVERY rank, and the line carries both attempts."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    calls = []
+
+    def make_attempt(rank, latch_on):
+        def attempt(p2p):
+            calls.append((rank, p2p))
+            if rank > 0:
+                return None, (p2p and rank in latch_on)
+            line = {"value": 100.0 if p2p else 80.0, "ms_per_step": 1.0,
+                    "config": {"parallelism": "tp2", "p2p_status": "ok", "p2p_handoff": "lean"}}
+            if p2p and 0 in latch_on:
+                line["config"]["p2p_status"] = "NvlError('... spin limit ...')"
+            return line, (p2p and 0 in latch_on)
+        return attempt
+
+    # nothing latched: one attempt, the P2P line is the result
+    r = bench.with_p2p_fallback(make_attempt(0, set()), agree=lambda f: f)
+    assert r["value"] == 100.0 and "tp_p2p_attempt" not in r and calls == [(0, True)]
+    # a latch on ANOTHER rank (rank 0 saw nothing): `agree` is the OR over ranks, rank 0 re-runs too
+    calls.clear()
+    r = bench.with_p2p_fallback(make_attempt(0, {1}), agree=lambda f: True)
+    assert calls == [(0, True), (0, False)]
+    assert r["value"] == 80.0 and r["tp_p2p_attempt"]["value_invalid"] == 100.0 and "fallback" in r["config"]["parallelism"]
+    # rank 0 latched: status travels into the record; a worker rank returns None from both attempts
+    calls.clear()
+    r = bench.with_p2p_fallback(make_attempt(0, {0}), agree=lambda f: f)
+    assert r["value"] == 80.0 and "spin limit" in r["tp_p2p_attempt"]["p2p_status"]
+    assert bench.with_p2p_fallback(make_attempt(1, {1}), agree=lambda f: f) is None and calls[-2:] == [(1, True), (1, False)]
+    assert r["value"] is not None
+
+    class NvlError(RuntimeError):
+        pass
+    assert bench._is_latched(NvlError("nvl error -2: nvl_allreduce: a peer did not arrive within the spin limit"))
+    assert not bench._is_latched(NvlError("something else")) and not bench._is_latched(RuntimeError("spin limit"))
+
+
+def test_bench_line_stays_compact(monkeypatch, tmp_path):
+    """The driver's record keeps only the tail of stdout: the one JSON line must stay well under 10 KB with all six extras
+    attached (round-4 review item 3) — the children's full lines and the prose notes live in side files."""
+    import json as _json
+    import subprocess
+    import types
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    child = {"metric": "m" * 60, "value": 17791.527986626046, "ms_per_step": 7529.76, "config": {"kv_blocks": 1234, "x": "y" * 900},
+             "roofline": {"frac": 0.3211111, "decode_step_frac_of_8TBps": 0.2351111, "kernel": "k" * 200},
+             "roofline_prefill": {"achieved": 447.3, "note": "n" * 300}}
+    monkeypatch.setattr(subprocess, "run", lambda cmd, **k: subprocess.CompletedProcess(cmd, 0, stdout=_json.dumps(child) + "\n", stderr=""))
+    monkeypatch.setattr(bench, "SIDE_DIR", str(tmp_path))
+    monkeypatch.setattr(bench, "BENCH_T0", __import__("time").perf_counter())
+    args = types.SimpleNamespace(gpu_memory_utilization=0.9)
+    fake_torch = types.SimpleNamespace(cuda=types.SimpleNamespace(empty_cache=lambda: None))
+    ex = bench.extra_configs(args, fake_torch)
+    assert set(ex) == {"config3", "config4_anchor", "config5", "tp8_rank_shape_bench", "tp4_rank_shape_bench",
+                       "tp8_rank_shape_16k_prompts"}
+    assert ex["config4_anchor"] == {"value": 17791.5, "ms": 7529.8, "attn": 0.321, "step": 0.235, "pf_TF": 447, "kv": 1234,
+                                    "wall": ex["config4_anchor"]["wall"]}
+    assert len(_json.dumps(ex)) < 1500
+    full = _json.load(open(tmp_path / "bench_extras_full.json"))
+    assert full["config3"]["config"]["x"] == "y" * 900                        # nothing is lost, it just is not on stdout
+    # an exhausted wall budget skips the remaining extras and says so
+    monkeypatch.setattr(bench, "BENCH_T0", __import__("time").perf_counter() - 10_000)
+    assert all("skipped" in v["error"] for v in bench.extra_configs(args, fake_torch).values())
+    assert len(_json.dumps(bench.NOTES)) < 6000 and bench.write_notes({}).startswith("gpurun_out/")
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # ops.P2PComm construction is collective: a rank that fails locally must still join the exchange and the barrier
 class _FakeCommLib:

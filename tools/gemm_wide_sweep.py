@@ -10,7 +10,11 @@ ops.load_library()
 BF16 = torch.bfloat16
 SHAPES = {"8b_qkv": (6144, 4096, 0), "8b_o": (4096, 4096, 2), "8b_down": (4096, 12288, 2), "8b_gate_up": (24576, 4096, 1),
           "32b_qkv": (10240, 5120, 0), "32b_o": (5120, 8192, 2), "32b_down": (5120, 25600, 2), "32b_gate_up": (51200, 5120, 1),
-          "32b_tp8_qkv": (1280, 5120, 0), "32b_tp8_gate_up": (6400, 5120, 1), "32b_tp8_down": (5120, 3200, 2)}
+          "32b_tp8_qkv": (1280, 5120, 0), "32b_tp8_gate_up": (6400, 5120, 1), "32b_tp8_down": (5120, 3200, 2),
+          # per-rank shapes of Qwen3-32B at TP = 4 (16 / 2 heads, intermediate 6400); the TP = 8 o_proj (K = 1024) runs on
+          # the skinny kernel
+          "32b_tp4_qkv": (2560, 5120, 0), "32b_tp4_o": (5120, 2048, 2), "32b_tp4_gate_up": (12800, 5120, 1),
+          "32b_tp4_down": (5120, 6400, 2)}
 
 
 def timeit(fn, iters=12):

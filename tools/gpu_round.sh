@@ -144,6 +144,35 @@ persistab)
   for p in 0 1 0 1; do NVL_PREFILL_PERSIST=$p timeout 300 python tools/prefill_bench.py > $OUT/prefill_persist${p}_$RANDOM.json 2> /dev/null; done;;
 prefillbench)
   timeout 600 python tools/prefill_bench.py > $OUT/prefill_bench.json 2> $OUT/prefill_bench.err; echo "prefill rc=$?"; cat $OUT/prefill_bench.json;;
+cumask)
+  # item (e) of the round-4 review: the externally launched TP = 2 stand-in (both ranks on the ONE GPU) latched a spin
+  # timeout in 4 of 8 runs. Same command, alternating: ranks on DISJOINT halves of the compute units (HSA_CU_MASK per
+  # rank, NVL_BENCH_CU_SPLIT=1) vs sharing all of them. One line per run: split, wall, p2p_status / value.
+  export NVL_BENCH_SHARE_GPU=1 NVL_BENCH_BACKEND=gloo
+  for i in ${CUMASK_RUNS:-1 0 1 0 1 0 1 1}; do
+    T0=$(date +%s); NVL_BENCH_CU_SPLIT=$i timeout 150 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port $((29540 + RANDOM % 200)) bench.py --gpus 2 --tp 2 --steps 1 --warmup 0 --num-seqs 48 --num-kvcache-blocks 300 --no-cpu-baseline --no-roofline > $OUT/cumask_run.json 2> $OUT/cumask_run.err; rc=$?
+    python - "$i" "$rc" "$(( $(date +%s) - T0 ))" $OUT/cumask_run.json $OUT/cumask_run.err >> $OUT/cumask_runs.jsonl <<'PY'
+import json, sys
+split, rc, wall, out, err = sys.argv[1:6]
+rec = {"cu_split": int(split), "rc": int(rc), "wall_s": int(wall)}
+try:
+    d = json.loads([ln for ln in open(out) if ln.startswith("{")][-1])
+    rec.update(value=d.get("value"), p2p_status=d["config"].get("p2p_status"), handoff=d["config"].get("p2p_handoff"))
+except Exception as ex:
+    rec["parse_error"] = repr(ex)
+e = open(err).read()
+rec["spin_limit_in_stderr"] = "spin limit" in e
+print(json.dumps(rec))
+PY
+    tail -1 $OUT/cumask_runs.jsonl
+  done
+  unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND;;
+lmhead256)
+  SWEEP_SHAPES=lm_head_8b timeout 600 python tools/gemm_wide_m256.py 160 208 256 > $OUT/lm_head_m160_m256.json 2> $OUT/lm_head_m160_m256.err; echo "lmhead256 rc=$?"; cat $OUT/lm_head_m160_m256.json;;
+pmcwaits)
+  # wave-cycle split of the prefill-attention kernel (same counters as profiles/r03_prefill_pmc_waits.json)
+  (cd /tmp && rm -rf /tmp/pmc_pf_waits && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_pf_waits -o pf -- python $REPO/tools/prefill_bench.py > $OUT/prefill_under_pmc_waits.json 2> $OUT/prefill_pmc_waits.err; echo "pmcwaits rc=$?"; tail -c 300 $OUT/prefill_pmc_waits.err)
+  f=$(find /tmp/pmc_pf_waits -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_group_summary.py $f prefill_attn $OUT/prefill_pmc_waits.json | tail -5;;
 *) echo "unknown step $w";;
 esac
 done
