@@ -305,7 +305,7 @@ int nvl_sample(const void* logits, int64_t logits_row_stride,
                uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                const uint64_t* row_keys,
                void* workspace, size_t workspace_bytes, void* stream);
-/* `row_keys` (nvl_sample, nvl_sample_shard, nvl_lmhead_sample; optional, may be NULL): device
+/* `row_keys` (nvl_sample, nvl_sample_shard; optional, may be NULL): device
  * uint64 [batch]. With it, row r of the batch draws as "row" = low 32 bits of row_keys[r] at
  * offset + (row_keys[r] >> 32) instead of as batch row r: a caller that passes
  * sequence_id | position << 32 gets draws that depend on (seed, sequence, position, column)
@@ -331,26 +331,6 @@ int nvl_sample_shard(const void* logits, int64_t logits_row_stride,
                      void* workspace, size_t workspace_bytes, void* stream);
 int nvl_sample_merge(const void* best_packed, int parts, int64_t part_stride_bytes,
                      int64_t* out, int64_t batch, void* stream);
-
-/* ---- lm_head GEMM + sampler in one pass (decode steps) -------------------------------------
- * Replaces ParallelLMHead.forward (layers/embed_head.py:56-66: logits = F.linear(x, weight))
- * followed by Sampler.forward (layers/sampler.py:7-12) as the engine runs them back to back
- * (engine/model_runner.py:212-218): the [batch, vocab] logits are never written to HBM; every
- * workgroup reduces its vocabulary columns to one {key, index} pair per row in the GEMM epilogue
- * and a second small kernel merges them. Same arithmetic and the same Philox draw as nvl_sample /
- * nvl_sample_shard on bf16-rounded logits (col_offset = global index of local column 0).
- *   x [batch, k] bf16 contiguous (batch <= 192); weight [vocab_local, k] bf16 contiguous.
- *   out (int64 [batch]) and/or best_packed ([batch][2] words, the shard's winner for
- *   nvl_sample_merge) — at least one; logits_out (optional, bf16 [batch, vocab_local]) also
- *   stores the rounded logits (tests / logit consumers).
- *   workspace: nvl_lmhead_sample_workspace_bytes(batch, vocab_local, k); 0 = shape not covered
- *   (the caller keeps GEMM + nvl_sample). */
-size_t nvl_lmhead_sample_workspace_bytes(int64_t batch, int64_t vocab_local, int k);
-int nvl_lmhead_sample(const void* x, const void* weight, const float* temperatures, int64_t* out,
-                      void* best_packed, void* logits_out, int64_t batch, int64_t vocab_local, int k,
-                      int64_t col_offset, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
-                      const uint64_t* row_keys,
-                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* Feed the previous step's sampled ids back as this step's input ids ON THE DEVICE:
  *   ids[i] = src_row[i] >= 0 ? prev_tokens[src_row[i]] : ids[i]

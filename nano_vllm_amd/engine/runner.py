@@ -273,10 +273,6 @@ class ModelRunner:
             # is left: a second copy of those weights is the price of a 4x cheaper weight stream per CU)
             self.packed_weight_bytes, self.packed_weight_skipped = self._pack_weights()
             self.sampler = Sampler(seed=config.seed, max_rows=config.max_num_seqs)
-            # decode micro-batching (see _forward_decode): second chain's stream, sampler and workspace
-            self.microbatches = int(os.environ.get("NVL_MICROBATCHES", "1")) if self.world_size == 1 else 1
-            self.side_stream = torch.cuda.Stream(device=self.device) if self.microbatches > 1 else None
-            self.sampler_b = Sampler(seed=config.seed + 0x9E3779B9, max_rows=config.max_num_seqs)
             self._alloc_stages()
             self.warmup_model()
             self.allocate_kv_cache()
@@ -421,13 +417,11 @@ class ModelRunner:
         ws_bytes = ops.paged_attn_decode_workspace_bytes(mb, self.geo["heads"], cfg.max_model_len)
         # zeroed once: the kernel's arrival counters live in it and are left at zero by every launch
         self.decode_ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
-        self.decode_ws_b = torch.zeros(ws_bytes, dtype=torch.uint8, device=self.device)
         # per-step work plan of the decode attention launches (ops.decode_plan): made once per step by the first
         # node of the decode graph, read by every layer's attention launch. NVL_DECODE_PLAN=0: every launch derives
         # its own schedule again (A/B measurements)
         self.use_plan = os.environ.get("NVL_DECODE_PLAN", "1") != "0"
         self.decode_plan = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
-        self.decode_plan_b = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
         self._step_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     # ------------------------------------------------------------------ warm-up + KV cache
@@ -583,14 +577,6 @@ class ModelRunner:
         """lm_head + sampler on the current stream; TP > 1: every rank samples its vocabulary shard and the
         per-row winners are merged on every rank (no [B, V] gather, embed_head.py:62-65)."""
         col0 = self.rank * self.geo["vocab_per_rank"]
-        ctx = get_context()
-        rows = hidden
-        if ctx.is_prefill:                                   # only each sequence's last token is sampled
-            rows = hidden[(ctx.cu_seqlens_q[1:] - 1).long()].contiguous()
-        # one pass over the vocabulary matrix, logits never in HBM (nvl_lmhead_sample); None = shape not covered
-        if sampler.forward_lm_head(rows, self.model.lm_head.weight, temps, out, col0, offset_dev=rng,
-                                   row_keys=rkey) is not None:
-            return
         if self.world_size == 1:
             sampler(self.model.compute_logits(hidden), temps, out=out, offset_dev=rng, row_keys=rkey)
         else:
@@ -613,30 +599,13 @@ class ModelRunner:
     def _forward_decode(self, bs: int):
         """Decode forward on the static device buffers (captured per bucket, or run eagerly): layers + lm_head
         + sampler, at any TP degree (the reference captures the layers only and runs lm_head, the logits
-        gather and the sampler eagerly, model_runner.py:212,218).
-
-        Micro-batching (NVL_MICROBATCHES=2, off by default; TP=1, bs >= 32): sequences are independent, so
-        the batch can be cut into two half-batches whose layer chains are forked onto two HIP streams (two
-        parallel branches of the same captured hipGraph), hoping that one chain's HBM-bound attention overlaps
-        the other's short latency-bound kernels. Measured on MI355X / ROCm 7.2 the branches do not overlap
-        usefully (27-30 k vs 31.7 k tok/s) while every small kernel and one pass over the weights are paid
-        twice; kept as a tested option (tests/test_e2e_gpu.py) for stacks where graph branches do run
-        concurrently."""
+        gather and the sampler eagerly, model_runner.py:212,218). (A micro-batched form — two half-batch chains on
+        two branches of the captured graph — was measured slower in rounds 1-3 and is gone: DESIGN.md, measured
+        negatives.)"""
         # input ids of sequences that were in the previous decode step come straight from its sampled ids
-        # (for the whole batch, BEFORE any chain of this step can overwrite tokens_dev)
         t = self.dstage.t
         ops.feed_tokens(t["ids"][:bs], t["src"][:bs], self.tokens_dev)
-        if self.microbatches > 1 and bs >= 32 and self.world_size == 1:
-            h = bs // 2
-            main = torch.cuda.current_stream()
-            side = self.side_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                self._decode_rows(h, bs, self.decode_ws_b, self.sampler_b, self.decode_plan_b if self.use_plan else None)
-            self._decode_rows(0, h, self.decode_ws, self.sampler, self.decode_plan if self.use_plan else None)
-            main.wait_stream(side)
-        else:
-            self._decode_rows(0, bs, self.decode_ws, self.sampler, self.decode_plan if self.use_plan else None)
+        self._decode_rows(0, bs, self.decode_ws, self.sampler, self.decode_plan if self.use_plan else None)
 
     @torch.inference_mode()
     def _launch_decode(self, n: int) -> None:

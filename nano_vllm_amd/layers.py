@@ -102,13 +102,6 @@ def get_rope(head_size: int, rotary_dim: int, max_position: int, base: float, de
 
 # NVL_FUSED_DECODE=0 keeps the separate q/k-norm+RoPE+KV-store launch on decode steps (A/B measurements)
 _FUSED_DECODE = os.environ.get("NVL_FUSED_DECODE", "1") != "0"
-# NVL_FUSED_LMHEAD=1 samples inside the lm_head GEMM's epilogue (nvl_lmhead_sample: logits never in HBM). Off by
-# default: measured on MI355X (profiles/r02_lmhead_bench.json) the hand-written wide-tile kernel is bit-compatible
-# with GEMM + nvl_sample but slower than hipBLASLt + nvl_sample at decode batch sizes (Qwen3-0.6B head, 131 rows:
-# 148 vs 127 us; 16 rows: 78 vs 78 us) — its time grows with the row count (LDS-fragment latency per row tile), not
-# with the bytes streamed.
-_FUSED_LMHEAD = os.environ.get("NVL_FUSED_LMHEAD", "0") == "1"
-
 
 class Attention(nn.Module):
     """Paged attention. `k_cache` / `v_cache` are injected by the runner; layout
@@ -179,7 +172,6 @@ class Sampler(nn.Module):
         self.max_rows = max_rows              # rows of the vocab-parallel winner buffers, allocated ONCE (graph-safe)
         self.calls = 0
         self._ws = None
-        self._lm_ws = None
         self.capture: list | None = None        # tests: every step's logits (fp32, host) are appended here
 
     def forward(self, logits: torch.Tensor, temperatures: torch.Tensor, out: torch.Tensor | None = None,
@@ -199,43 +191,6 @@ class Sampler(nn.Module):
             self.capture.append(logits.float().cpu())
         return ops.sample(logits, temperatures, self.seed, offset, self._ws, out=out, offset_dev=offset_dev,
                           row_keys=row_keys)
-
-    def forward_lm_head(self, hidden: torch.Tensor, weight: torch.Tensor, temperatures: torch.Tensor, out: torch.Tensor,
-                        col_offset: int = 0, offset_dev: torch.Tensor | None = None,
-                        row_keys: torch.Tensor | None = None) -> torch.Tensor | None:
-        """lm_head GEMM + sampling in one pass (nvl_lmhead_sample): `hidden` [B, K] are the rows to sample from,
-        `weight` this rank's [V/tp, K] lm_head shard. Returns None when the shape is not covered (B > 192): the
-        caller then runs the GEMM and `forward` / `forward_shard`. TP > 1: the shard winners are exchanged and
-        merged as in `forward_shard`."""
-        b, k = hidden.shape
-        v = weight.shape[0]
-        if not (_FUSED_LMHEAD and hidden.is_cuda and hidden.dtype == torch.bfloat16 and hidden.is_contiguous()):
-            return None
-        need = ops.lmhead_sample_workspace_bytes(b, v, k)
-        if need == 0:
-            return None
-        # sized ONCE for the largest covered batch of either tiling: captured graphs keep pointing at it
-        need = max(ops.lmhead_sample_workspace_bytes(144, v, k), ops.lmhead_sample_workspace_bytes(192, v, k))
-        if self._lm_ws is None or self._lm_ws.numel() < need or self._lm_ws.device != hidden.device:
-            self._lm_ws = torch.empty(need, dtype=torch.uint8, device=hidden.device)
-        offset = 0 if offset_dev is not None else self.calls
-        self.calls += 1
-        logits = None
-        if self.capture is not None:
-            logits = torch.empty((b, v), dtype=torch.bfloat16, device=hidden.device)
-        _, size = tp.world()
-        if size == 1:
-            ops.lmhead_sample(hidden, weight, temperatures, self.seed, offset, self._lm_ws, out=out, logits_out=logits,
-                              offset_dev=offset_dev, row_keys=row_keys)
-        else:
-            self._pair_buffers(b, size, hidden.device)
-            ops.lmhead_sample(hidden, weight, temperatures, self.seed, offset, self._lm_ws, out_packed=self._mine,
-                              logits_out=logits, col_offset=col_offset, offset_dev=offset_dev, row_keys=row_keys)
-            tp.all_gather_small(self._mine, self._pairs)
-            ops.sample_merge(self._pairs, size, b, out)
-        if logits is not None:
-            self.capture.append(logits.float().cpu())
-        return out
 
     def _pair_buffers(self, b: int, size: int, device) -> None:
         """Select (allocating on first use, never regrowing) the {key, index} winner buffers for a b-row step:
@@ -365,8 +320,7 @@ _flush: dict[int, torch.Tensor] = {}
 
 def _scratch(nbytes: int, device: torch.device) -> torch.Tensor | None:
     """Split-K slab scratch of the wide kernel's bf16 / SiLU modes: one tensor per distinct (size, stream), never freed
-    or regrown (captured graphs hold its address). Per STREAM because two decode chains may run the same shapes
-    concurrently (NVL_MICROBATCHES=2: two branches of one graph, captured from two streams) and must not share slabs."""
+    or regrown (captured graphs hold its address). Per STREAM: launches on different streams must not share slabs."""
     if not nbytes:
         return None
     key = (nbytes, device.index, torch.cuda.current_stream(device).cuda_stream)

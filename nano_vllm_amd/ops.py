@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnvl_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # name -> (restype, argtypes); mirrors include/nvl.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -59,9 +59,6 @@ SIGNATURES = {
     "nvl_sample_shard": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_uint64, c_uint64,
                                  c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nvl_sample_merge": (c_int, [c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p]),
-    "nvl_lmhead_sample_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
-    "nvl_lmhead_sample": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
-                                  c_int64, c_uint64, c_uint64, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "nvl_feed_tokens": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "nvl_allreduce_create": (c_int, [c_int, c_int, c_int64, ctypes.POINTER(c_void_p)]),
     "nvl_allreduce_uid": (c_int, [c_void_p, c_void_p]),
@@ -486,32 +483,6 @@ def sample_merge(packed: torch.Tensor, parts: int, batch: int, out: torch.Tensor
     assert packed.stride(2) == 1 and packed.stride(1) == 2 and out.dtype == torch.int64
     _check(lib().nvl_sample_merge(packed.data_ptr(), parts, packed.stride(0) * 4, out.data_ptr(), batch, _stream()))
     return out
-
-
-def lmhead_sample_workspace_bytes(batch: int, vocab_local: int, k: int) -> int:
-    """Workspace of the fused lm_head + sampler for this shape; 0 = not covered (keep GEMM + sample)."""
-    return lib().nvl_lmhead_sample_workspace_bytes(batch, vocab_local, k)
-
-
-def lmhead_sample(x: torch.Tensor, weight: torch.Tensor, temperatures: torch.Tensor, seed: int, offset: int,
-                  workspace: torch.Tensor, out: torch.Tensor | None = None, out_packed: torch.Tensor | None = None,
-                  logits_out: torch.Tensor | None = None, col_offset: int = 0,
-                  offset_dev: torch.Tensor | None = None, row_keys: torch.Tensor | None = None):
-    """Sample from softmax((x @ weight.T) / T) without materialising the logits (x [B, K], weight [V, K] bf16)."""
-    _dev(x, "x")
-    assert x.dim() == 2 and x.is_contiguous() and weight.is_contiguous()
-    assert x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and temperatures.dtype == torch.float32
-    b, k = x.shape
-    v = weight.shape[0]
-    assert weight.shape[1] == k and (out is not None or out_packed is not None)
-    assert logits_out is None or (logits_out.shape == (b, v) and logits_out.is_contiguous() and logits_out.dtype == torch.bfloat16)
-    _check(lib().nvl_lmhead_sample(
-        x.data_ptr(), weight.data_ptr(), temperatures.data_ptr(), out.data_ptr() if out is not None else None,
-        out_packed.data_ptr() if out_packed is not None else None,
-        logits_out.data_ptr() if logits_out is not None else None, b, v, k, col_offset, seed & 0xFFFFFFFFFFFFFFFF,
-        offset & 0xFFFFFFFFFFFFFFFF, offset_dev.data_ptr() if offset_dev is not None else None, _keys_ptr(row_keys, b),
-        workspace.data_ptr(), workspace.numel() * workspace.element_size(), _stream()))
-    return out if out is not None else out_packed
 
 
 class P2PComm:

@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for sym in _declared():
         assert hasattr(lib, sym), f"{sym} declared in include/nvl.h but not exported"
     lib.nvl_abi_version.restype = ctypes.c_int
-    assert lib.nvl_abi_version() == 3
+    assert lib.nvl_abi_version() == 4
 
 
 def test_ctypes_binding_matches_header():
@@ -66,10 +66,8 @@ def test_host_side_argument_validation_without_gpu():
     assert lib.nvl_linear_decode_splits(64, 1024, 2048, 2) == 4
     assert lib.nvl_linear_decode_splits(144, 6144, 1024, 1) == 1
     assert lib.nvl_linear_decode_splits(144, 6144, 4096, 0) == 0          # deep-K shapes: not this kernel's (nvl_linear_wide)
-    # collectives: a communicator must be created and connected first; lm_head sampler reports uncovered shapes
+    # collectives: a communicator must be created and connected first
     assert lib.nvl_allreduce_run(None, 16, 16, 4, 1024, None) == -1
-    assert lib.nvl_lmhead_sample_workspace_bytes(131, 151936, 1024) == 594 * 131 * 8
-    assert lib.nvl_lmhead_sample_workspace_bytes(300, 151936, 1024) == 0
     assert lib.nvl_linear_decode(16, 16, 16, 144, 6144, 4096, 0, 0, None) == -3 and b"not covered" in lib.nvl_last_error()
     assert lib.nvl_linear_decode(None, 16, 16, 144, 4096, 1024, 0, 0, None) == -1
     # wide-tile deep-K linear: plan query works without a GPU; uncovered shapes are EUNSUPPORTED, null pointers EINVAL

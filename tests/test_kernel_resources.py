@@ -51,11 +51,8 @@ def test_attention_kernels_keep_two_waves_per_simd(kernels):
         assert r["vgpr_count"] <= 128, (r["name"], r["vgpr_count"])
     # the prefill kernel's budget after this round's work: <= 216 registers in every instantiation —
     # the zero-fill / waterfall regressions of the past showed up as +20-40 registers first
-    # (the persistent instantiations — last template argument true — also keep the next item's coordinates, the tile list
-    #  and a second set of buffer descriptors live across the tile loop: <= 248, still two waves per SIMD)
     for r in _named(kernels, "prefill_attn_kernel"):
-        persist = re.search(r"prefill_attn_kernelILb\dELb\dELi\dELb1E", r["name"]) is not None
-        assert r["vgpr_count"] <= (248 if persist else 216), (r["name"], r["vgpr_count"])
+        assert r["vgpr_count"] <= 216, (r["name"], r["vgpr_count"])
 
 
 def test_skinny_gemm_register_budget(kernels):
@@ -100,7 +97,7 @@ def test_prefill_kernel_isa_has_none_of_the_patterns_this_project_removed():
     import kernel_resources
     import re
     dis = kernel_resources.disassemble(build.build(), "prefill_attn_kernel")
-    assert len(dis) == 9, sorted(dis)        # {paged, paged fp8, packed} x {4 waves, 8 waves, 4 waves persistent}
+    assert len(dis) == 6, sorted(dis)        # {paged, paged fp8, packed} x {4 waves, 8 waves}
     for name, text in dis.items():
         assert text.count("v_mfma_f32_32x32x16_bf16") == 64, name          # two unrolled tiles x 32 MFMAs, nothing else
         assert text.count("s_cbranch_execnz") <= 2, (name, "waterfall loops")

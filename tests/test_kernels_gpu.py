@@ -618,45 +618,6 @@ def test_prefill_paged_prefix(ops, hq, hkv, lq_lk):
     assert float((lse.cpu() - lse_ref).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1), (32, 8)])
-@pytest.mark.parametrize("lens", [[1024] * 16, [561] * 29, [100, 1000, 33, 257, 640, 129, 128, 1], [300] * 64])
-def test_prefill_persistent_walk_is_bit_identical_to_the_plain_launch(ops, hq, hkv, lens, monkeypatch):
-    """The persistent form of the prefill kernel (workgroups walk the longest-first item list in a snake and prefetch the
-    next item's first K/V tile and Q rows; taken by itself for equal-length batches, NVL_PREFILL_PERSIST=0|1 forces it)
-    does the same arithmetic per item: output and LSE must equal the plain launch bit for bit — packed K/V and, for the
-    ragged case, the paged cache (chunk continuation) as well — and both must match the oracle."""
-    gen = g(60 + len(lens))
-    n = sum(lens)
-    q = torch.randn(n, hq, 128, generator=gen).to(BF16)
-    k = torch.randn(n, hkv, 128, generator=gen).to(BF16)
-    v = torch.randn(n, hkv, 128, generator=gen).to(BF16)
-    cu = _cu(lens)
-    scale = 128 ** -0.5
-    outs = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("NVL_PREFILL_PERSIST", mode)
-        lse = torch.zeros(n, hq, dtype=torch.float32, device="cuda")
-        o = ops.attn_prefill_varlen(dev(q), dev(k), dev(v), dev(cu), dev(cu), max(lens), scale, lse=lse)
-        outs[mode] = (o.cpu(), lse.cpu())
-    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
-    if n <= 4096:
-        o_ref = ref.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, scale)
-        assert float((outs["1"][0].float() - o_ref.float()).abs().max()) <= 2e-2 * float(o_ref.float().abs().max()) + 1e-3
-    if len(lens) == 8:                                   # paged: queries continue a cached prefix
-        lqs = [max(1, l // 3) for l in lens]
-        kc, vc, bt = _paged_setup(lens, hkv, 256, seed=61)
-        qp = torch.randn(sum(lqs), hq, 128, generator=gen).to(BF16)
-        cuq = _cu(lqs)
-        res = {}
-        for mode in ("0", "1"):
-            monkeypatch.setenv("NVL_PREFILL_PERSIST", mode)
-            res[mode] = ops.attn_prefill_varlen(dev(qp), dev(ref.to_head_major(kc)), dev(ref.to_head_major(vc)), dev(cuq),
-                                                dev(cu), max(lqs), scale, block_tables=dev(bt)).cpu()
-        assert torch.equal(res["0"], res["1"])
-        o_ref = ref.flash_attn_varlen_func(qp, kc, vc, max(lqs), cuq, max(lens), cu, scale, True, bt)
-        assert float((res["1"].float() - o_ref.float()).abs().max()) <= 2e-2 * float(o_ref.float().abs().max()) + 1e-3
-
-
 def test_prefill_softmax_rescale_branch(ops):
     """Force a large running-max jump at a late tile (guide §5.4 rule 26): spike one key."""
     hq = hkv = 8
@@ -1133,43 +1094,6 @@ def test_sampler_shards_merge_to_the_full_row_draw(ops):
         ops.sample_merge(packed, parts, b, out)
         assert torch.equal(out.cpu(), full), parts
     assert int(full[3]) == 100
-
-
-@pytest.mark.parametrize("b", [1, 16, 17, 131, 144, 145, 192])
-@pytest.mark.parametrize("v,k", [(151936, 1024), (4104, 384), (2048, 4096), (2048, 5120)])
-def test_lmhead_sample_fused_equals_gemm_then_sample(ops, b, v, k):
-    """nvl_lmhead_sample (logits never in HBM) vs the two-step path on ITS OWN rounded logits: the stored logits
-    must be the bf16-rounded fp32 product (GEMM-class tolerance), and the sampled ids must equal nvl_sample run on
-    those stored logits exactly (same keys, same Philox draw, same tie rule) — T > 0 and T = 0 rows mixed, ragged
-    last column group (4104 = 16 * 256 + 8), both tilings (b <= 144: 256 columns per workgroup, else 128), K blocks of 8 / 3 / 5 steps."""
-    gen = g(90 + b)
-    x = (torch.randn(b, k, generator=gen) * 0.5).to(BF16)
-    w = (torch.randn(v, k, generator=gen) * 0.05).to(BF16)
-    temps = torch.tensor([0.0 if i % 4 == 1 else 0.5 + 0.1 * (i % 7) for i in range(b)])
-    need = ops.lmhead_sample_workspace_bytes(b, v, k)
-    assert need > 0
-    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
-    logits = torch.empty(b, v, dtype=BF16, device="cuda")
-    out = torch.empty(b, dtype=torch.int64, device="cuda")
-    ops.lmhead_sample(dev(x), dev(w), dev(temps), seed=21, offset=9, workspace=ws, out=out, logits_out=logits)
-    acc = dev(x).float() @ dev(w).float().t()
-    assert _close_to_rounded(logits.cpu(), acc.cpu(), atol=1e-4)
-    ws2 = torch.empty(ops.sample_workspace_bytes(512), dtype=torch.uint8, device="cuda")
-    want = ops.sample(logits, dev(temps), seed=21, offset=9, workspace=ws2)
-    assert torch.equal(out.cpu(), want.cpu())
-    # without logits_out the result is the same, and a shard (col_offset) merges to the same winner
-    out2 = torch.empty_like(out)
-    ops.lmhead_sample(dev(x), dev(w), dev(temps), seed=21, offset=9, workspace=ws, out=out2)
-    assert torch.equal(out2.cpu(), want.cpu())
-    if v % 16 == 0:
-        half = v // 2
-        packed = torch.zeros(2, 512, 2, dtype=torch.int32, device="cuda")
-        for r in range(2):
-            ops.lmhead_sample(dev(x), dev(w)[r * half:(r + 1) * half].contiguous(), dev(temps), seed=21, offset=9,
-                              workspace=ws, out_packed=packed[r], col_offset=r * half)
-        out3 = torch.empty_like(out)
-        ops.sample_merge(packed, 2, b, out3)
-        assert torch.equal(out3.cpu(), want.cpu())
 
 
 def test_feed_tokens(ops):

@@ -67,60 +67,3 @@ def test_in_register_tile_list_is_the_reversed_list_of_all_q_blocks():
             continue
         want = [(i, b) for i, n in enumerate(lens) for b in range((n + 127) // 128)]
         assert tile_list(lens) == want[::-1]
-
-
-# ---------------------------------------------------------------------------------------------------------------
-# The PERSISTENT form (round 4): workgroup bx of a grid of nb workgroups walks blocks bx, 2 nb - 1 - bx, 2 nb + bx, ...
-# (a snake over the longest-first numbering) until the first block whose tile rank is past the end of the list.
-def snake_walk(bx, nb, total_ranks, hq, hkv):
-    """kernel find_next(): the (head, tile_rank) items workgroup bx processes, in order."""
-    g_sz = hq // hkv
-    items, rnd = [], 0
-    while True:
-        b = (rnd + 1) * nb - 1 - bx if rnd & 1 else rnd * nb + bx
-        xcd, slot = b & 7, b >> 3
-        gi, g = divmod(slot, g_sz)
-        j = gi * 8 + xcd
-        rank, kvh = divmod(j, hkv)
-        if rank >= total_ranks:
-            return items
-        items.append((kvh * g_sz + g, rank, b))
-        rnd += 1
-
-
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (64, 8), (8, 8), (2, 1)])
-@pytest.mark.parametrize("tiles", [1, 5, 64, 128, 145, 1000])
-def test_persistent_snake_walk_visits_every_item_exactly_once(hq, hkv, tiles):
-    """Launcher: blocks = ceil(tiles x Hkv / 8) x 8 x G, grid = min(blocks, 2 x CUs = 512). Every (q-head, tile rank) with
-    rank < tiles is processed by exactly one workgroup; a workgroup stops at its FIRST invalid block — valid only because
-    ranks never decrease along a walk; the heads of a kv group keep meeting on one physical XCD (block ids that differ
-    by 8 map to physical workgroups that differ by 8, forwards and backwards)."""
-    g_sz = hq // hkv
-    blocks = (tiles * hkv + 7) // 8 * 8 * g_sz
-    nb = min(blocks, 512)
-    seen = {}
-    for bx in range(nb):
-        walk = snake_walk(bx, nb, tiles, hq, hkv)
-        ranks = [r for _, r, _ in walk]
-        assert ranks == sorted(ranks)                       # longest first within a walk too
-        for head, rank, b in walk:
-            assert (head, rank) not in seen
-            seen[(head, rank)] = bx
-    assert sorted(seen) == sorted(itertools.product(range(hq), range(tiles)))
-    if nb % 8 == 0:
-        for (head, rank), bx in seen.items():
-            mate = seen[(head // g_sz * g_sz, rank)]        # first head of the same (tile, kv-head) group
-            assert mate & 7 == bx & 7                       # same physical XCD
-
-
-def test_persistent_snake_walk_balances_uniform_batches():
-    """Equal-length sequences and an even number of full rounds (what the launcher requires before it takes the persistent
-    form by itself): the tiles a workgroup processes differ by at most one q-block's worth between any two workgroups.
-    Work of an item = its q-block index + 1 (causal: key tiles grow with the q-block); ranks are longest-first."""
-    seqs, qblocks, hq, hkv = 16, 8, 16, 8                   # 16 x 1024 tokens, Qwen3-0.6B heads: 2048 items, 512 workgroups
-    tiles = seqs * qblocks
-    order = [(s, b) for s in range(seqs) for b in range(qblocks)][::-1]           # tile rank -> (sequence, q-block)
-    work = []
-    for bx in range(512):
-        work.append(sum(order[rank][1] + 1 for _, rank, _ in snake_walk(bx, 512, tiles, hq, hkv)))
-    assert max(work) - min(work) <= qblocks

@@ -31,8 +31,6 @@ gemm)
   timeout 600 python tools/gemm_bench.py > $OUT/gemm_bench.json 2> $OUT/gemm_bench.err; echo "gemm rc=$?"; tail -c 1500 $OUT/gemm_bench.err; cat $OUT/gemm_bench.json;;
 retest)
   timeout 1200 python -m pytest tests/test_tp_gpu.py tests/test_kernels_gpu.py -m gpu -q -rf -k "tp2 or long or continuation or shards or linear_decode or p2p" > $OUT/pytest_retest.log 2>&1; echo "retest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed" $OUT/pytest_retest.log | tail -20;;
-lmhead)
-  timeout 600 python tools/lmhead_bench.py > $OUT/lmhead_bench.json 2> $OUT/lmhead_bench.err; echo "lmhead rc=$?"; tail -c 600 $OUT/lmhead_bench.err; cat $OUT/lmhead_bench.json;;
 prefillx)
   for x in 0 1; do NVL_PREFILL_XCD=$x timeout 600 python tools/prefill_bench.py > $OUT/prefill_xcd$x.json 2> $OUT/prefill_xcd$x.err; echo "prefill xcd=$x rc=$?"; cat $OUT/prefill_xcd$x.json; echo; done;;
 newtests)
@@ -140,8 +138,6 @@ widesweep)
   timeout 900 python tools/gemm_wide_sweep.py ${SWEEP_M:-131 144 256} > $OUT/gemm_wide_sweep.jsonl 2> $OUT/gemm_wide_sweep.err; echo "sweep rc=$?";;
 skinnysweep)
   timeout 600 python tools/gemm_skinny_sweep.py ${SWEEP_M:-64 131 208} > $OUT/skinny_sweep.jsonl 2> $OUT/skinny_sweep.err; echo "skinny sweep rc=$?";;
-persistab)
-  for p in 0 1 0 1; do NVL_PREFILL_PERSIST=$p timeout 300 python tools/prefill_bench.py > $OUT/prefill_persist${p}_$RANDOM.json 2> /dev/null; done;;
 prefillbench)
   timeout 600 python tools/prefill_bench.py > $OUT/prefill_bench.json 2> $OUT/prefill_bench.err; echo "prefill rc=$?"; cat $OUT/prefill_bench.json;;
 cumask)
