@@ -260,7 +260,15 @@ int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stride,
                                 int block_size, int64_t num_blocks, int64_t max_context,
                                 float softmax_scale,
                                 void* workspace, size_t workspace_bytes,
-                                int kv_dtype, const void* plan, float* lse, void* stream);
+                                int kv_dtype, const void* plan, float* lse,
+                                int qkv_splits, int64_t qkv_split_stride, void* stream);
+/* qkv_splits (ABI 4): 0 = `qkv` is the bf16 output [batch, qkv_tok_stride] of the qkv projection
+ * (QKVParallelLinear.forward, layers/linear.py:96-128). 1..8 = `qkv` is the fp32 split-K slab stack
+ * [qkv_splits][batch][qkv_tok_stride] that nvl_linear_wide mode 2 leaves for a deep-K projection
+ * (slab s at element offset s * qkv_split_stride): the attention prologue sums a row piece over the
+ * slabs in slab order and rounds it to bf16 once — the value the separate slab-reduce launch would
+ * have produced, bit for bit — before the norm / rotation. Matrix-core kernel only (Hq / Hkv in
+ * {2, 4, 8}); other group sizes return NVL_EUNSUPPORTED. */
 
 /* ---- Varlen causal prefill attention (MFMA) ----------------------------------
  * Replaces flash_attn_varlen_func as called at layers/attention.py:67-70:

@@ -163,7 +163,48 @@ struct FusedArgs {              // only read by the FUSED instantiation
   const float* cos_sin;
   int64_t max_pos;
   float eps;
+  // qkv_splits > 0 (matrix-core kernel only): `qkv` is not the bf16 GEMM output but the fp32 split-K slabs
+  // [splits][batch][qkv_tok_stride] of nvl_linear_wide mode 2 (slab s starts qkv_split_stride elements after slab s - 1):
+  // a row piece is summed over the slabs in slab order and rounded to bf16 once — exactly what slab_reduce_kernel would
+  // have written — before the norm / rotation. The separate reduce launch of the qkv projection disappears.
+  int qkv_splits;
+  int qkv_split_stride;         // elements (< 2^31: checked by the entry point)
 };
+
+// 8 consecutive elements of a qkv row: bf16 as stored, or the rounded sum of the fp32 split-K slabs. The slab pieces are
+// requested FOUR SLABS AT A TIME before the first add (clamped index, predicated add): a runtime loop of load -> add would
+// pay one dependent L2 round trip per slab on the critical path of every segment prologue (measured: +9 us per launch on
+// the one-kv-head shape with 5 slabs). Sum order is slab 0, 1, 2, ... — slab_reduce_kernel's.
+template <bool SLABS>
+__device__ __forceinline__ u32x4_t load_qkv8(const bf16_t* base, int64_t elt, const FusedArgs& fa) {
+  if constexpr (!SLABS) {
+    return *reinterpret_cast<const u32x4_t*>(base + elt);
+  } else {
+    const float* p = reinterpret_cast<const float*>(base) + elt;
+    const int S = fa.qkv_splits;
+    // (stride and slab index live in VECTOR registers: the kernel sits at its scalar-register limit, and wave-uniform
+    //  64-bit slab addresses would spill SGPRs)
+    int stride_v;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(stride_v) : "s"(fa.qkv_split_stride));
+    f32x4_t a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < S; s0 += 4) {
+      f32x4_t ta[4], tb[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int off = (s0 + j < S ? s0 + j : S - 1) * stride_v;
+        ta[j] = *reinterpret_cast<const f32x4_t*>(p + off);
+        tb[j] = *reinterpret_cast<const f32x4_t*>(p + off + 4);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (s0 + j < S) {
+          a = s0 + j == 0 ? ta[j] : a + ta[j];                    // (slab 0 starts the sum: 0 + x would turn -0.0 into +0.0)
+          b = s0 + j == 0 ? tb[j] : b + tb[j];
+        }
+    }
+    return u32x4_t{pack_bf16x2(a[0], a[1]), pack_bf16x2(a[2], a[3]), pack_bf16x2(b[0], b[1]), pack_bf16x2(b[2], b[3])};
+  }
+}
 
 template <int G, bool FUSED>
 __global__ __launch_bounds__(256, G == 4 ? 2 : 1) void decode_stream_kernel(   // G = 4: stay within 256 VGPRs
@@ -633,7 +674,7 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 // KV8: the cache holds OCP fp8 e4m3 rows of 128 bytes (opt-in, see decode_stream_fp8_kernel): a tile is loaded as
 // 8 rows x 16 elements per wave instruction and converted (exactly) to bf16 on its way into the wave's LDS tile; the
 // new token's k / v are quantised before they enter this step's softmax. Everything after the LDS write is unchanged.
-template <bool FUSED, bool KV8, int G = 8>
+template <bool FUSED, bool KV8, int G = 8, bool SLABS = false>
 __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
     int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
@@ -777,7 +818,8 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     {
       RopeRegs rr = {};
       u32x4_t wq = {0u, 0u, 0u, 0u}, wk = {0u, 0u, 0u, 0u};
-      const bf16_t* row = FUSED ? q + (int64_t)b * fa.qkv_tok_stride : q + (int64_t)b * hq * 128;
+      const bf16_t* row = q + (int64_t)b * hq * 128;                 // (unfused: q [batch, hq, 128])
+      const int64_t row_e = FUSED ? (int64_t)b * fa.qkv_tok_stride : 0;    // fused: element offset of the token's qkv row
       if constexpr (FUSED) {
         int64_t pos = len - 1;
         pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
@@ -791,14 +833,17 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         qh[it] = u32x4_t{0u, 0u, 0u, 0u};
-        if (rq + 4 * it < G) qh[it] = *reinterpret_cast<const u32x4_t*>(row + (h * G + rq + 4 * it) * 128 + sub * 8);
+        if (rq + 4 * it < G) {
+          if constexpr (FUSED) qh[it] = load_qkv8<SLABS>(q, row_e + (h * G + rq + 4 * it) * 128 + sub * 8, fa);
+          else qh[it] = *reinterpret_cast<const u32x4_t*>(row + (h * G + rq + 4 * it) * 128 + sub * 8);
+        }
         if constexpr (FUSED) qh[it] = norm_rope_head_regs(qh[it], fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
         *reinterpret_cast<u32x4_t*>(k_lds + (rq + 4 * it) * 256 + sub * 16) = qh[it];   // q tile [8 heads][128]
       }
       if constexpr (FUSED) {
         if (owns_last) {
-          u32x4_t knew = *reinterpret_cast<const u32x4_t*>(row + (hq + h) * 128 + sub * 8);
-          const u32x4_t vnew = *reinterpret_cast<const u32x4_t*>(row + (hq + hkv + h) * 128 + sub * 8);
+          u32x4_t knew = load_qkv8<SLABS>(q, row_e + (hq + h) * 128 + sub * 8, fa);
+          const u32x4_t vnew = load_qkv8<SLABS>(q, row_e + (hq + hkv + h) * 128 + sub * 8, fa);
           knew = norm_rope_head_regs(knew, fa.k_norm_w != nullptr, wk, fa.eps, rr, sub);
           const int tl = len - 1;
           if constexpr (KV8) {
@@ -1070,10 +1115,29 @@ inline int64_t mfma8_grid(int64_t batch, int hkv, int64_t max_context, bool plan
   return grid < 1 ? 1 : grid;
 }
 
+template <bool FUSED, bool KV8, int G, bool SLABS>
+int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
+                          void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
+                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse);
+
+// qkv as fp32 split-K slabs (fa.qkv_splits > 0) is an instantiation of its own: the bf16 form keeps its registers
 template <bool FUSED, bool KV8, int G = 8>
 int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                         void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
                         void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse) {
+  if constexpr (FUSED) {
+    if (fa.qkv_splits > 0)
+      return launch_decode_mfma8_s<FUSED, KV8, G, true>(q, kc, vc, bt, bt_stride, ctx, out, batch, hkv, block_size, max_context,
+                                                        scale, workspace, s, fa, plan, lse);
+  }
+  return launch_decode_mfma8_s<FUSED, KV8, G, false>(q, kc, vc, bt, bt_stride, ctx, out, batch, hkv, block_size, max_context,
+                                                     scale, workspace, s, fa, plan, lse);
+}
+
+template <bool FUSED, bool KV8, int G, bool SLABS>
+int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
+                          void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
+                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse) {
   const int hq = hkv * G;
   const int slots = stream_slots(max_context);
   float* part_o = (float*)workspace;
@@ -1084,7 +1148,7 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_kernel<FUSED, KV8, G>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_kernel<FUSED, KV8, G, SLABS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the G = 8 kernel");
       return NVL_ELAUNCH;
@@ -1093,7 +1157,7 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
   }
   NVL_REQUIRE(lds <= 160 * 1024, "nvl_paged_attn_decode: batch=%lld needs %zu B of LDS (> 160 KiB)", (long long)batch, lds);
   const int64_t grid = mfma8_grid(batch, hkv, max_context, plan != nullptr);
-  hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
+  hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
                      (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
                      block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
@@ -1249,6 +1313,14 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
   NVL_REQUIRE(workspace_bytes >= need, "%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   const FusedArgs none = {};
+  if (fa && fa->qkv_splits > 0) {
+    // fp32 split-K slabs as the qkv input: only the matrix-core kernel's prologue sums them
+    const bool mfma = (G == 8 && (kv_dtype == NVL_KV_FP8 || !use_valu_g8())) || ((G == 2 || G == 4) && use_mfma_small_g());
+    if (!mfma) {
+      nvl_set_error("%s: qkv_splits > 0 needs the matrix-core kernel (Hq/Hkv in {2, 4, 8}; got %d)", who, G);
+      return NVL_EUNSUPPORTED;
+    }
+  }
   if (kv_dtype == NVL_KV_FP8) {
 #define NVL_DECODE8_CASE(GG)                                                                                           \
   case GG:                                                                                                             \
@@ -1353,8 +1425,13 @@ extern "C" int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stri
                                            int num_q_heads, int num_kv_heads, int block_size, int64_t num_blocks,
                                            int64_t max_context, float softmax_scale, void* workspace,
                                            size_t workspace_bytes, int kv_dtype, const void* plan, float* lse,
-                                           void* stream) {
+                                           int qkv_splits, int64_t qkv_split_stride, void* stream) {
   const char* who = "nvl_paged_attn_decode_fused";
+  NVL_REQUIRE(qkv_splits >= 0 && qkv_splits <= 8, "%s: qkv_splits=%d (0 = bf16 qkv, 1..8 = fp32 split-K slabs)", who, qkv_splits);
+  NVL_REQUIRE(qkv_splits <= 1 || qkv_split_stride >= batch * qkv_tok_stride, "%s: qkv_split_stride=%lld < batch x qkv_tok_stride",
+              who, (long long)qkv_split_stride);
+  NVL_REQUIRE(qkv_splits == 0 || (int64_t)qkv_splits * qkv_split_stride < (1ll << 31), "%s: qkv slabs of %lld elements exceed 32-bit offsets",
+              who, (long long)qkv_split_stride);
   NVL_REQUIRE(cos_sin && max_pos > 0, "%s: rope table required", who);
   NVL_REQUIRE((q_norm_w == nullptr) == (k_norm_w == nullptr), "%s: q/k norm weights must both be set or both NULL", who);
   NVL_REQUIRE(qkv_tok_stride % 8 == 0 && qkv_tok_stride >= (int64_t)(num_q_heads + 2 * num_kv_heads) * 128, "%s: bad qkv stride", who);
@@ -1366,6 +1443,8 @@ extern "C" int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stri
   fa.cos_sin = cos_sin;
   fa.max_pos = max_pos;
   fa.eps = eps;
+  fa.qkv_splits = qkv_splits;
+  fa.qkv_split_stride = (int)qkv_split_stride;
   return decode_common(qkv, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch, num_q_heads,
                        num_kv_heads, block_size, num_blocks, max_context, softmax_scale, workspace, workspace_bytes,
                        stream, &fa, who, kv_dtype, plan, lse);

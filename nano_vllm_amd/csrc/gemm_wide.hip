@@ -48,6 +48,7 @@
 //     1 KiB contiguous (each 16-lane group 2 lines) and the weight stream costs a quarter of the address-path time.
 // Rounding points are the reference's: the GEMM output is rounded to bf16 before the activation.
 #include "common.h"
+#include "gemm_tile.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -85,7 +86,7 @@ template <int MT, int NT, int NW, int EPI, int RING, bool PACKED, int BK = 128>
 __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
                                                                      const bf16_t* __restrict__ w,
                                                                      void* __restrict__ out, int M, int N, int K,
-                                                                     int steps, int paired_tiles) {
+                                                                     int steps, int paired_tiles, int dbg) {
   static_assert(BK == 128 || BK == 64, "k columns per step");
   constexpr int kKB = BK / 32;                                    // (shadows the file-scope constants: per-step geometry)
   constexpr int kBK = BK;
@@ -125,6 +126,9 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
     s = (s < last ? s : last) + rot;
     return s >= steps ? s - steps : s;
   };
+  // (measurement switches, NVL_WIDE_DBG: bit 0 = the loader stages step 0 only, bit 1 = every weight load re-reads step 0's
+  //  lines — each stream alone inside the real pipeline; results are garbage)
+  const bool dbg_no_x = dbg & 1, dbg_no_w = dbg & 2;
 
   if (wave >= NW) {
     // ---- loader wave(s): x tile of step s + 2 -> LDS stage (s + 2) % 3 while the consumers work on step s --------
@@ -156,6 +160,7 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
       x_src[i] = grow * K + (chunk << 3);
     }
     auto issue = [&](int s) {
+      if (dbg_no_x && s > 0) return;
       const unsigned dst = lds0 + (unsigned)(s % NS) * kStage + (unsigned)lw * 1024;
       const bf16_t* src = xb + kstep(s) * kBK;
 #pragma unroll
@@ -229,7 +234,7 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
 
   u32x4_t wf[RING][NT][kKB];
   auto wload = [&](u32x4_t (*dst)[kKB], int s) {
-    s = kstep(s);
+    s = dbg_no_w ? 0 : kstep(s);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -249,7 +254,7 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
     constexpr int PT = NT == 1 ? 2 : 1;
     constexpr int NG = (MT + PT - 1) / PT;
     constexpr int L = NT * kKB;                                   // weight loads per step
-    const int ks = LOAD ? kstep(sl) : 0;
+    const int ks = LOAD && !dbg_no_w ? kstep(sl) : 0;
     u32x4_t f[2][PT][kKB];
     auto fread = [&](int g, u32x4_t (*dst)[kKB]) {
 #pragma unroll
@@ -394,6 +399,7 @@ __global__ __launch_bounds__(256) void pack_weight_tiles_kernel(const bf16_t* __
 struct WidePlan {
   int mt, nt, nw, mgroups, tiles, split, steps;   // tiles = workgroups along N; steps = bk-wide k steps per workgroup
   int bk;                                         // k columns per step: 128, or 64 (wide_bk)
+  int tile;                                       // 1: the tiled form (gemm_tile.hip) runs this shape — with `split`, on packed weights
 };
 
 // Weight ring depth. 5 waves (NW = 4) share 4 SIMDs, so those kernels live in 256 registers: one set less at 7+ row
@@ -475,9 +481,47 @@ constexpr TunedPlan kTuned[] = {
     {10240, 5120, EPI_BF16, 2, 9, 2, 3, 2},
     {10240, 5120, EPI_BF16, 13, 16, 2, 3, 1},
     {4096, 4096, EPI_PARTIAL, 13, 13, 2, 4, 4},
+    // per-rank qkv of Qwen3-32B at TP = 8 / TP = 4 as fp32 slabs for the fused decode attention (round 5: the attention
+    // prologue sums them, so FEW slabs matter more than the last microsecond of the GEMM — every wave of the attention
+    // grid reads (G + 2) x 512 B per slab): sweep profiles/r05_gemm_wide_sweep_tp_rank_shapes.jsonl, us incl. the reduce
+    // launch these plans no longer need: TP8 split 4 (nt 1, nw 3) 14.6 vs the model's split 8 14.3 at 144 rows; 13-16
+    // row tiles split 4 (nt 1, nw 4) 15.8; TP4 split 4 (nt 1, nw 4) 17.4 vs split 5 17.9, 13-16 row tiles nt 2 nw 3 split 4 21.3
+    {1280, 5120, EPI_PARTIAL, 1, 9, 1, 3, 4},
+    {1280, 5120, EPI_PARTIAL, 10, 16, 1, 4, 4},
+    {2560, 5120, EPI_PARTIAL, 1, 9, 1, 4, 4},
+    {2560, 5120, EPI_PARTIAL, 10, 16, 2, 3, 4},
+    // per-rank gate_up / down at TP = 8 / TP = 4 (same sweep; us, model's pick -> measured best): TP8 gate_up 64-144 rows
+    // split 5 -> 4 (22.3 -> 21.5 / 28.0 -> 27.4); TP4 down 64 rows split 2 -> nt 2 nw 4 split 5 (19.1 -> 16.4)
+    {6400, 5120, EPI_SILU, 2, 9, 2, 4, 4},
+    {5120, 6400, EPI_PARTIAL, 2, 9, 2, 4, 5},
 };
 
-bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
+// K split of the TILED form (gemm_tile.hip: 128 weight rows per workgroup, 64-column stages): enough workgroups to fill
+// the chip (>= ~3/4 of 256), stages of >= 8 per workgroup, slab traffic kept small — the smallest divisor of k / 128 that
+// reaches 192 workgroups, else the largest one that keeps 8 stages.
+int tile_split(int n, int k, int mode) {
+  const int wgs = nvl_tile_workgroups(n, mode), units = k / 128;
+  int best = 1;
+  for (int s = 1; s <= 16; ++s) {
+    if (units % s || k / 64 / s < 8) continue;
+    best = s;
+    if (wgs * s >= 192) break;
+  }
+  return best;
+}
+
+// Rows from which the tiled form is taken (NVL_WIDE_TILE=0 never, =1 from 33 rows on; default: the measured crossover)
+int tile_min_rows() {
+  static const int v = [] {
+    const char* e = getenv("NVL_WIDE_TILE");
+    if (e && e[0] == '0') return 1 << 30;
+    if (e && e[0] == '1') return 33;
+    return 1 << 30;
+  }();
+  return v;
+}
+
+bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best, int force_split_arg = 0) {
   if (m < 1 || m > 1024 || n < 16 || k < kBK || k % kBK) return false;
   if (m * (int64_t)k >= (1ll << 31) || (int64_t)n * k >= (1ll << 40)) return false;   // 32-bit x element offsets in the loader
   if (mode == EPI_SILU ? n % 32 : n % 16) return false;
@@ -485,7 +529,7 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
   const int mtiles = (int)((m + 15) / 16);
   const int force_bk = env_int("NVL_WIDE_BK", 0) == 128 ? 128 : 0;
   int force_nt = env_int("NVL_WIDE_NT", 0), force_nw = env_int("NVL_WIDE_NW", 0);
-  int force_split = env_int("NVL_WIDE_SPLIT", 0);
+  int force_split = force_split_arg ? force_split_arg : env_int("NVL_WIDE_SPLIT", 0);
   if (!force_nt && !force_nw && !force_split && env_int("NVL_WIDE_TUNED", 1))
     for (const TunedPlan& t : kTuned)
       if (t.n == n && t.k == k && t.mode == mode && mtiles >= t.mtiles_lo && mtiles <= t.mtiles_hi) {
@@ -532,6 +576,20 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
     best->bk = 64;
     best->steps *= 2;
   }
+  if (best_t < 1e30) best->tile = 0;
+  if (best_t < 1e30 && !force_split_arg && m >= tile_min_rows() && nvl_tile_covers(m, n, k, mode)) {
+    // the tiled form takes the shape; the streaming plan is re-made with ITS split so that a launch on row-major weights
+    // (which the tiled form does not read) produces the same number of slabs the plan query promised
+    const int ts = tile_split(n, k, mode);
+    WidePlan q;
+    if (wide_plan(m, n, k, mode, &q, ts)) {
+      *best = q;
+      best->tile = 1;
+    }
+  }
+  if (best_t < 1e30 && env_int("NVL_WIDE_DEBUG", 0) && best->tile)
+    fprintf(stderr, "nvl_linear_wide plan m=%lld n=%d k=%d mode=%d: TILED form, split=%d -> %d wgs\n", (long long)m, n, k, mode,
+            best->split, nvl_tile_workgroups(n, mode) * best->split);
   if (best_t < 1e30 && env_int("NVL_WIDE_DEBUG", 0))
     fprintf(stderr, "nvl_linear_wide plan m=%lld n=%d k=%d mode=%d: nt=%d nw=%d mt=%d groups=%d tiles=%d split=%d steps=%d x %d -> %d wgs, model %.1f us\n",
             (long long)m, n, k, mode, best->nt, best->nw, best->mt, best->mgroups, best->tiles, best->split, best->steps, best->bk,
@@ -555,14 +613,15 @@ int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, in
   }
   // two row groups: pair them on one XCD (see the kernel); NVL_WIDE_PAIR=0 keeps the plain (tile, split, group) grid
   static const bool pair_ok = env_int("NVL_WIDE_PAIR", 1) != 0;
+  static const int dbg = env_int("NVL_WIDE_DBG", 0);
   if (p.mgroups == 2 && pair_ok) {
     const unsigned gx = (unsigned)((p.tiles + 7) / 8) * 16;
     hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK>), dim3(gx, p.split, 1),
-                       dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, p.tiles);
+                       dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, p.tiles, dbg);
     return NVL_OK;
   }
   hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK>), dim3(p.tiles, p.split, p.mgroups),
-                     dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, 0);
+                     dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, 0, dbg);
   return NVL_OK;
 }
 
@@ -647,11 +706,17 @@ extern "C" int nvl_linear_wide(const void* x, const void* weight, void* out, int
     return NVL_EUNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
+  const bool tiled = p.tile && g_packed;
   if (mode == EPI_PARTIAL) {
-    const int rc = dispatch_wide<EPI_PARTIAL>(p, x, weight, out, m, n, k, s);
+    const int rc = tiled ? nvl_tile_launch(x, weight, out, m, n, k, EPI_PARTIAL, p.split, stream)
+                         : dispatch_wide<EPI_PARTIAL>(p, x, weight, out, m, n, k, s);
     return rc != NVL_OK ? rc : nvl_check_launch("nvl_linear_wide");
   }
   if (p.split == 1) {
+    if (tiled) {
+      const int rc = nvl_tile_launch(x, weight, out, m, n, k, mode, 1, stream);
+      return rc != NVL_OK ? rc : nvl_check_launch("nvl_linear_wide");
+    }
     const int rc = mode == EPI_SILU ? dispatch_wide<EPI_SILU>(p, x, weight, out, m, n, k, s)
                                     : dispatch_wide<EPI_BF16>(p, x, weight, out, m, n, k, s);
     return rc != NVL_OK ? rc : nvl_check_launch("nvl_linear_wide");
@@ -666,7 +731,8 @@ extern "C" int nvl_linear_wide(const void* x, const void* weight, void* out, int
     const int cols = q.nw * q.nt * 16;
     q.tiles = (n + cols - 1) / cols;
   }
-  int rc = dispatch_wide<EPI_PARTIAL>(q, x, weight, workspace, m, n, k, s);
+  int rc = tiled ? nvl_tile_launch(x, weight, workspace, m, n, k, EPI_PARTIAL, p.split, stream)
+                 : dispatch_wide<EPI_PARTIAL>(q, x, weight, workspace, m, n, k, s);
   if (rc != NVL_OK) return rc;
   const int out_cols = mode == EPI_SILU ? n / 2 : n;
   const int64_t quads = m * (int64_t)(out_cols / 4);

@@ -121,14 +121,20 @@ class Attention(nn.Module):
             ops.store_kvcache(k, v, self.k_cache, self.v_cache, ctx.slot_mapping)
         return self._attend(q, k, v, ctx)
 
+    def fuses_decode_step(self, ctx) -> bool:
+        """Does `forward_fused` take the one-launch decode path (norm + rope + KV store inside the attention kernel) for
+        this step? Only then may `qkv` arrive as fp32 split-K slabs (QKVParallelLinear.forward_for_fused_decode)."""
+        return not ctx.is_prefill and self.k_cache.numel() > 0 and _FUSED_DECODE
+
     # -- fused entry point: raw qkv GEMM output -> (q/k norm, rope, KV store) in one launch -------
     def forward_fused(self, qkv: torch.Tensor, positions: torch.Tensor, q_norm_w, k_norm_w, eps: float,
                       rope_table: torch.Tensor) -> torch.Tensor:
         ctx = get_context()
-        n = qkv.shape[0]
+        n = qkv.shape[-2]             # ([S,] N, (Hq + 2 Hkv) * 128): fp32 split-K slabs only on the fused decode path
         hq, hkv = self.num_heads, self.num_kv_heads
         has_cache = self.k_cache.numel() > 0
-        if not ctx.is_prefill and has_cache and _FUSED_DECODE:
+        assert qkv.dim() == 2 or self.fuses_decode_step(ctx)
+        if self.fuses_decode_step(ctx):
             # decode step: norm + rope + KV store happen inside the attention kernel (position and slot
             # of each sequence's new token follow from context_lens / block_tables)
             ws = ctx.decode_workspace
@@ -472,6 +478,29 @@ class QKVParallelLinear(ColumnParallelLinear):
         kv_rows = self.num_kv_heads * self.head_size
         off, size = {"q": (0, q_rows), "k": (q_rows, kv_rows), "v": (q_rows + kv_rows, kv_rows)}[shard_id]
         param.data.narrow(0, off, size).copy_(self._my_slice(loaded, 0))
+
+
+    def forward_for_fused_decode(self, x: torch.Tensor) -> torch.Tensor:
+        """The qkv projection of a decode step whose consumer is the fused attention kernel: where the deep-K GEMM splits
+        K over workgroups anyway (Qwen3-8B / 32B, full width or per rank), its fp32 slabs [S, N, out] go straight to the
+        attention prologue, which sums and rounds them (ops.paged_attn_decode_fused) — the slab-reduce launch between
+        the two disappears (5 us + a launch boundary per layer on the per-rank shapes of Qwen3-32B at TP = 8). Same
+        bits as forward(): the reduce kernel's sum order and rounding point are the prologue's. NVL_QKV_SLABS=0 keeps
+        the reduce launch (A/B)."""
+        if (_QKV_SLABS and self.bias is None and _decode_sized(x)
+                and ops.decode_attention_takes_qkv_slabs(self.num_heads, self.num_kv_heads)):
+            m, k = x.shape
+            n = self.weight.shape[0]
+            if not ops.linear_decode_splits(m, n, k, ops.LINEAR_BF16):       # (the skinny kernel never leaves slabs)
+                plain = ops.linear_wide_plan(m, n, k, ops.LINEAR_BF16) if k % 128 == 0 else None
+                slabs = ops.linear_wide_plan(m, n, k, ops.LINEAR_PARTIAL) if plain else None
+                if (plain and plain[0] > 1 and slabs and slabs[0] <= 8
+                        and _use_wide(x, self.weight, ops.LINEAR_PARTIAL, self.weight_packed)):
+                    return decode_linear(x, self.weight, ops.LINEAR_PARTIAL, packed=self.weight_packed)
+        return self.forward(x)
+
+
+_QKV_SLABS = os.environ.get("NVL_QKV_SLABS", "1") != "0"
 
 
 class RowParallelLinear(LinearBase):

@@ -49,7 +49,7 @@ SIGNATURES = {
     "nvl_paged_attn_decode_fused": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p,
                                             c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                             c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int, c_void_p,
-                                            c_void_p, c_void_p]),
+                                            c_void_p, c_int, c_int64, c_void_p]),
     "nvl_attn_prefill_varlen": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p,
                                         c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_int64, c_float,
                                         c_int, c_void_p, c_void_p]),
@@ -383,22 +383,39 @@ def paged_attn_decode_fused(qkv: torch.Tensor, q_norm_w, k_norm_w, eps: float, c
                             workspace: torch.Tensor, out: torch.Tensor | None = None,
                             plan: torch.Tensor | None = None, lse: torch.Tensor | None = None) -> torch.Tensor:
     """Decode step in one launch: q/k-norm + RoPE (position = context_len - 1) + KV-cache store of the
-    new token + paged attention. qkv: raw qkv GEMM output [B, (Hq + 2*Hkv)*128]."""
+    new token + paged attention. qkv: raw qkv GEMM output [B, (Hq + 2*Hkv)*128] bf16 — or, for a deep-K projection,
+    the fp32 split-K slabs [S, B, (Hq + 2*Hkv)*128] of `linear_wide(..., LINEAR_PARTIAL)` (S <= 8; summed and rounded
+    in the attention prologue: no separate slab-reduce launch; matrix-core kernel only, Hq / Hkv in {2, 4, 8})."""
     _dev(qkv, "qkv")
-    assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.dtype == torch.bfloat16
+    splits, split_stride = 0, 0
+    if qkv.dtype == torch.float32:
+        assert qkv.dim() == 3 and qkv.is_contiguous() and 1 <= qkv.shape[0] <= 8
+        splits, split_stride = qkv.shape[0], qkv.stride(0)
+        b, row_stride = qkv.shape[1], qkv.stride(1)
+    else:
+        assert qkv.dim() == 2 and qkv.stride(1) == 1 and qkv.dtype == torch.bfloat16
+        b, row_stride = qkv.shape[0], qkv.stride(0)
     assert block_tables.dtype == torch.int32 and context_lens.dtype == torch.int32 and block_tables.stride(1) == 1
     assert cos_sin.dtype == torch.float32 and cos_sin.is_contiguous()
-    b = qkv.shape[0]
     if out is None:
-        out = torch.empty((b, num_q_heads, 128), dtype=qkv.dtype, device=qkv.device)
+        out = torch.empty((b, num_q_heads, 128), dtype=torch.bfloat16, device=qkv.device)
     _check(lib().nvl_paged_attn_decode_fused(
-        qkv.data_ptr(), qkv.stride(0), q_norm_w.data_ptr() if q_norm_w is not None else None,
+        qkv.data_ptr(), row_stride, q_norm_w.data_ptr() if q_norm_w is not None else None,
         k_norm_w.data_ptr() if k_norm_w is not None else None, eps, cos_sin.data_ptr(), cos_sin.shape[0],
         k_cache.data_ptr(), v_cache.data_ptr(), block_tables.data_ptr(), block_tables.stride(0),
         context_lens.data_ptr(), out.data_ptr(), b, num_q_heads, k_cache.shape[1], k_cache.shape[2], k_cache.shape[0],
         max_context, scale, workspace.data_ptr(), workspace.numel() * workspace.element_size(), kv_dtype_of(k_cache),
-        plan.data_ptr() if plan is not None else None, _lse_ptr(lse, (b, num_q_heads)), _stream()))
+        plan.data_ptr() if plan is not None else None, _lse_ptr(lse, (b, num_q_heads)), splits, split_stride, _stream()))
     return out
+
+
+def decode_attention_takes_qkv_slabs(num_q_heads: int, num_kv_heads: int) -> bool:
+    """Can `paged_attn_decode_fused` sum fp32 qkv slabs itself for this head geometry? (the matrix-core kernel: group
+    sizes 2, 4, 8 unless the packed-dot forms are forced by NVL_DECODE_MFMA=0 / NVL_DECODE_G8_VALU=1)"""
+    g = num_q_heads // max(num_kv_heads, 1)
+    if g == 8:
+        return os.environ.get("NVL_DECODE_G8_VALU", "0") != "1"
+    return g in (2, 4) and os.environ.get("NVL_DECODE_MFMA", "1") != "0"
 
 
 def attn_prefill_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor,

@@ -24,6 +24,7 @@ import torch
 from torch import nn
 
 from .api import model_geometry
+from .attn_meta import get_context
 from .layers import (Attention, MergedColumnParallelLinear, ParallelLMHead, QKVParallelLinear, RMSNorm,
                      RowParallelLinear, SiluAndMul, VocabParallelEmbedding, get_rope)
 from . import tp
@@ -47,7 +48,10 @@ class Qwen3Attention(nn.Module):
             self.k_norm = RMSNorm(self.head_dim, eps=self.eps)
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
-        qkv = self.qkv_proj(hidden_states)
+        if self.attn.fuses_decode_step(get_context()):
+            qkv = self.qkv_proj.forward_for_fused_decode(hidden_states)      # bf16 [N, out], or fp32 split-K slabs
+        else:
+            qkv = self.qkv_proj(hidden_states)
         qw = self.q_norm.weight if self.has_qk_norm else None
         kw = self.k_norm.weight if self.has_qk_norm else None
         o = self.attn.forward_fused(qkv, positions, qw, kw, self.eps, self.rotary_emb.cos_sin_cache)

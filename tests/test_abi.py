@@ -52,11 +52,21 @@ def test_host_side_argument_validation_without_gpu():
     assert rc == -3 and b"group size" in lib.nvl_last_error()
     # fused decode entry: rope table is mandatory; q/k norm weights come as a pair
     rc = lib.nvl_paged_attn_decode_fused(16, 4096, None, None, 1e-6, None, 0, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
-                                         4096, 0.1, 16, 1 << 30, 0, None, None, None)
+                                         4096, 0.1, 16, 1 << 30, 0, None, None, 0, 0, None)
     assert rc == -1 and b"rope table" in lib.nvl_last_error()
     rc = lib.nvl_paged_attn_decode_fused(16, 4096, 16, None, 1e-6, 16, 4096, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
-                                         4096, 0.1, 16, 1 << 30, 0, None, None, None)
+                                         4096, 0.1, 16, 1 << 30, 0, None, None, 0, 0, None)
     assert rc == -1 and b"both be set or both NULL" in lib.nvl_last_error()
+    # qkv as fp32 split-K slabs: at most 8, a slab at least one [batch, row] image long, matrix-core group sizes only
+    rc = lib.nvl_paged_attn_decode_fused(16, 4096, None, None, 1e-6, 16, 4096, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
+                                         4096, 0.1, 16, 1 << 30, 0, None, None, 9, 1 << 20, None)
+    assert rc == -1 and b"qkv_splits" in lib.nvl_last_error()
+    rc = lib.nvl_paged_attn_decode_fused(16, 4096, None, None, 1e-6, 16, 4096, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
+                                         4096, 0.1, 16, 1 << 30, 0, None, None, 2, 100, None)
+    assert rc == -1 and b"qkv_split_stride" in lib.nvl_last_error()
+    rc = lib.nvl_paged_attn_decode_fused(16, 4096, None, None, 1e-6, 16, 4096, 16, 16, 16, 16, 16, 16, 4, 8, 8, 256, 8,
+                                         4096, 0.1, 16, 1 << 30, 0, None, None, 2, 1 << 20, None)
+    assert rc == -3 and b"matrix-core" in lib.nvl_last_error()          # Hq / Hkv = 1: the packed-dot kernel
     # per-step decode plan: buffer size is validated on the host
     rc = lib.nvl_decode_plan(16, 4, 16, 8, 4096, 16, 8, None)
     assert rc == -1 and b"plan buffer" in lib.nvl_last_error()

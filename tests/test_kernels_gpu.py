@@ -260,6 +260,24 @@ def test_linear_wide_forced_plans_agree(ops, monkeypatch):
     ops._wide_cache.clear()
 
 
+def test_linear_wide_tiled_form_in_its_own_process():
+    """The TILED form of nvl_linear_wide (csrc/gemm_tile.hip: both operands through LDS by LDS-DMA, 8 waves on the
+    matrix pipe) on every shape family and row count it covers, forced on with NVL_WIDE_TILE=1 in a process of its own
+    (the switch is read once): bf16 / SiLU / slab outputs against the fp32 product at the streaming form's bars, ragged
+    last workgroups, K splits, and agreement with the streaming form on row-major weights (tools/gemm_tile_check.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NVL_WIDE_TILE="1")
+    cp = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_tile_check.py")], capture_output=True, text=True,
+                        env=env, timeout=900)
+    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+    assert lines, cp.stderr[-2000:]
+    res = json.loads(lines[-1])
+    assert cp.returncode == 0 and not res["bad"], res
+
+
 def test_linear_wide_unsupported_shapes_are_reported(ops):
     assert ops.linear_wide_plan(16, 4096, 1000, ops.LINEAR_BF16) is None       # K not a multiple of 128
     assert ops.linear_wide_plan(16, 4100, 1024, ops.LINEAR_BF16) is None       # N not a multiple of 16
@@ -499,6 +517,72 @@ def test_paged_attn_decode_fused_equals_unfused(ops, hq, hkv, lens, with_norm):
         assert torch.equal(o3, o2)
     if live:
         assert float((lse.cpu()[live] - lse_ref[live]).abs().max()) <= 2e-3
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (16, 2)])
+@pytest.mark.parametrize("splits", [1, 2, 5, 8])
+@pytest.mark.parametrize("kv", ["bf16", "fp8"])
+def test_paged_attn_decode_fused_sums_qkv_split_k_slabs(ops, hq, hkv, splits, kv):
+    """Round 5: the fused decode attention takes the qkv projection as the fp32 split-K slabs of nvl_linear_wide mode 2
+    ([S, B, (Hq + 2 Hkv) * 128]) and sums + rounds them in its prologue — what the slab-reduce launch between the two
+    kernels used to do (reference: the bf16 F.linear output of QKVParallelLinear, layers/linear.py:96-128, feeding
+    qwen3.py:83-85 + attention.py:63,72-74). Same sum order (slab 0, 1, ...) and one rounding => output, K cache and V
+    cache are bit-identical to the launch on the reduced bf16 matrix, with and without a plan; padded rows stay zero."""
+    bs, max_ctx = 256, 2048
+    gen = g(44 + splits)
+    lens = [1, 255, 256, 257, 0, 1024, 1500, 33, 2048]
+    b = len(lens)
+    nb = [(n + bs - 1) // bs for n in lens]
+    total = sum(nb) + 2
+    dt = torch.float8_e4m3fn if kv == "fp8" else BF16
+    kc = (torch.randn(total, hkv, bs, 128, generator=gen) * 0.5).to(dt)
+    vc = (torch.randn(total, hkv, bs, 128, generator=gen) * 0.5).to(dt)
+    perm = torch.randperm(total, generator=gen).tolist()
+    bt = torch.full((b, max_ctx // bs), -1, dtype=torch.int32)
+    c = 0
+    for s_, n in enumerate(nb):
+        for j in range(n):
+            bt[s_, j] = perm[c]
+            c += 1
+    width = (hq + 2 * hkv) * 128
+    slabs = dev(torch.randn(splits, b, width, generator=gen) / splits ** 0.5)
+    acc = slabs[0].clone()
+    for s_ in range(1, splits):
+        acc += slabs[s_]                               # fp32, slab order: slab_reduce_kernel's order
+    qkv = acc.to(BF16)
+    qw = dev((1 + 0.1 * torch.randn(128, generator=gen)).to(BF16))
+    kw = dev((1 + 0.1 * torch.randn(128, generator=gen)).to(BF16))
+    inv = 1.0 / (1e6 ** (torch.arange(0, 128, 2).float() / 128))
+    table = dev(torch.cat([(torch.arange(max_ctx).float()[:, None] * inv[None]).cos(),
+                           (torch.arange(max_ctx).float()[:, None] * inv[None]).sin()], -1).contiguous())
+    ctx, btd = dev(torch.tensor(lens, dtype=torch.int32)), dev(bt)
+    scale = 128 ** -0.5
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, max_ctx), dtype=torch.uint8, device="cuda")
+    assert ops.decode_attention_takes_qkv_slabs(hq, hkv)
+    outs = []
+    for src in (qkv, slabs):
+        for planned in (False, True):
+            k1, v1 = dev(kc.clone()), dev(vc.clone())
+            plan = ops.decode_plan(ctx, hq, hkv, max_ctx) if planned else None
+            o = ops.paged_attn_decode_fused(src, qw, kw, 1e-6, table, k1, v1, btd, ctx, hq, scale, max_ctx,
+                                            torch.zeros_like(ws), plan=plan)
+            torch.cuda.synchronize()
+            outs.append((o, k1.view(torch.uint8), v1.view(torch.uint8)))
+    for o, k1, v1 in outs[1:]:
+        assert torch.equal(o, outs[0][0]) and torch.equal(k1, outs[0][1]) and torch.equal(v1, outs[0][2])
+    assert not outs[2][0][4].any() and outs[2][0][0].any()          # the padded row stays zero, live rows are written
+
+
+def test_paged_attn_decode_fused_refuses_slabs_for_the_packed_dot_kernel(ops):
+    """Hq / Hkv = 1 runs on the packed-dot kernel, whose prologue reads bf16 only: slabs are refused, not misread."""
+    assert not ops.decode_attention_takes_qkv_slabs(8, 8)
+    slabs = torch.zeros(2, 1, 24 * 128, device="cuda")
+    kc = torch.zeros(2, 8, 256, 128, dtype=BF16, device="cuda")
+    table = torch.zeros(256, 128, device="cuda")
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(1, 8, 256), dtype=torch.uint8, device="cuda")
+    with pytest.raises(ops.NvlError):
+        ops.paged_attn_decode_fused(slabs, None, None, 1e-6, table, kc, kc.clone(), torch.zeros(1, 1, dtype=torch.int32, device="cuda"),
+                                    torch.ones(1, dtype=torch.int32, device="cuda"), 8, 0.1, 256, ws)
 
 
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (16, 2), (8, 1), (32, 8)])

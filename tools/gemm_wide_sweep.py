@@ -34,7 +34,7 @@ def timeit(fn, iters=12):
     return s.elapsed_time(e) / iters * 1e3
 
 
-def main():
+def main():  # noqa: C901
     ms = [int(a) for a in sys.argv[1:]] or [144]
     only = os.environ.get("SWEEP_SHAPES")
     for name, (n, k, mode) in SHAPES.items():
