@@ -48,7 +48,6 @@
 //     1 KiB contiguous (each 16-lane group 2 lines) and the weight stream costs a quarter of the address-path time.
 // Rounding points are the reference's: the GEMM output is rounded to bf16 before the activation.
 #include "common.h"
-#include "gemm_tile.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -399,7 +398,6 @@ __global__ __launch_bounds__(256) void pack_weight_tiles_kernel(const bf16_t* __
 struct WidePlan {
   int mt, nt, nw, mgroups, tiles, split, steps;   // tiles = workgroups along N; steps = bk-wide k steps per workgroup
   int bk;                                         // k columns per step: 128, or 64 (wide_bk)
-  int tile;                                       // 1: the tiled form (gemm_tile.hip) runs this shape — with `split`, on packed weights
 };
 
 // Weight ring depth. 5 waves (NW = 4) share 4 SIMDs, so those kernels live in 256 registers: one set less at 7+ row
@@ -496,32 +494,7 @@ constexpr TunedPlan kTuned[] = {
     {5120, 6400, EPI_PARTIAL, 2, 9, 2, 4, 5},
 };
 
-// K split of the TILED form (gemm_tile.hip: 128 weight rows per workgroup, 64-column stages): enough workgroups to fill
-// the chip (>= ~3/4 of 256), stages of >= 8 per workgroup, slab traffic kept small — the smallest divisor of k / 128 that
-// reaches 192 workgroups, else the largest one that keeps 8 stages.
-int tile_split(int n, int k, int mode) {
-  const int wgs = nvl_tile_workgroups(n, mode), units = k / 128;
-  int best = 1;
-  for (int s = 1; s <= 16; ++s) {
-    if (units % s || k / 64 / s < 8) continue;
-    best = s;
-    if (wgs * s >= 192) break;
-  }
-  return best;
-}
-
-// Rows from which the tiled form is taken (NVL_WIDE_TILE=0 never, =1 from 33 rows on; default: the measured crossover)
-int tile_min_rows() {
-  static const int v = [] {
-    const char* e = getenv("NVL_WIDE_TILE");
-    if (e && e[0] == '0') return 1 << 30;
-    if (e && e[0] == '1') return 33;
-    return 1 << 30;
-  }();
-  return v;
-}
-
-bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best, int force_split_arg = 0) {
+bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
   if (m < 1 || m > 1024 || n < 16 || k < kBK || k % kBK) return false;
   if (m * (int64_t)k >= (1ll << 31) || (int64_t)n * k >= (1ll << 40)) return false;   // 32-bit x element offsets in the loader
   if (mode == EPI_SILU ? n % 32 : n % 16) return false;
@@ -529,7 +502,7 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best, int force_spli
   const int mtiles = (int)((m + 15) / 16);
   const int force_bk = env_int("NVL_WIDE_BK", 0) == 128 ? 128 : 0;
   int force_nt = env_int("NVL_WIDE_NT", 0), force_nw = env_int("NVL_WIDE_NW", 0);
-  int force_split = force_split_arg ? force_split_arg : env_int("NVL_WIDE_SPLIT", 0);
+  int force_split = env_int("NVL_WIDE_SPLIT", 0);
   if (!force_nt && !force_nw && !force_split && env_int("NVL_WIDE_TUNED", 1))
     for (const TunedPlan& t : kTuned)
       if (t.n == n && t.k == k && t.mode == mode && mtiles >= t.mtiles_lo && mtiles <= t.mtiles_hi) {
@@ -576,20 +549,6 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best, int force_spli
     best->bk = 64;
     best->steps *= 2;
   }
-  if (best_t < 1e30) best->tile = 0;
-  if (best_t < 1e30 && !force_split_arg && m >= tile_min_rows() && nvl_tile_covers(m, n, k, mode)) {
-    // the tiled form takes the shape; the streaming plan is re-made with ITS split so that a launch on row-major weights
-    // (which the tiled form does not read) produces the same number of slabs the plan query promised
-    const int ts = tile_split(n, k, mode);
-    WidePlan q;
-    if (wide_plan(m, n, k, mode, &q, ts)) {
-      *best = q;
-      best->tile = 1;
-    }
-  }
-  if (best_t < 1e30 && env_int("NVL_WIDE_DEBUG", 0) && best->tile)
-    fprintf(stderr, "nvl_linear_wide plan m=%lld n=%d k=%d mode=%d: TILED form, split=%d -> %d wgs\n", (long long)m, n, k, mode,
-            best->split, nvl_tile_workgroups(n, mode) * best->split);
   if (best_t < 1e30 && env_int("NVL_WIDE_DEBUG", 0))
     fprintf(stderr, "nvl_linear_wide plan m=%lld n=%d k=%d mode=%d: nt=%d nw=%d mt=%d groups=%d tiles=%d split=%d steps=%d x %d -> %d wgs, model %.1f us\n",
             (long long)m, n, k, mode, best->nt, best->nw, best->mt, best->mgroups, best->tiles, best->split, best->steps, best->bk,
@@ -706,17 +665,11 @@ extern "C" int nvl_linear_wide(const void* x, const void* weight, void* out, int
     return NVL_EUNSUPPORTED;
   }
   hipStream_t s = (hipStream_t)stream;
-  const bool tiled = p.tile && g_packed;
   if (mode == EPI_PARTIAL) {
-    const int rc = tiled ? nvl_tile_launch(x, weight, out, m, n, k, EPI_PARTIAL, p.split, stream)
-                         : dispatch_wide<EPI_PARTIAL>(p, x, weight, out, m, n, k, s);
+    const int rc = dispatch_wide<EPI_PARTIAL>(p, x, weight, out, m, n, k, s);
     return rc != NVL_OK ? rc : nvl_check_launch("nvl_linear_wide");
   }
   if (p.split == 1) {
-    if (tiled) {
-      const int rc = nvl_tile_launch(x, weight, out, m, n, k, mode, 1, stream);
-      return rc != NVL_OK ? rc : nvl_check_launch("nvl_linear_wide");
-    }
     const int rc = mode == EPI_SILU ? dispatch_wide<EPI_SILU>(p, x, weight, out, m, n, k, s)
                                     : dispatch_wide<EPI_BF16>(p, x, weight, out, m, n, k, s);
     return rc != NVL_OK ? rc : nvl_check_launch("nvl_linear_wide");
@@ -731,8 +684,7 @@ extern "C" int nvl_linear_wide(const void* x, const void* weight, void* out, int
     const int cols = q.nw * q.nt * 16;
     q.tiles = (n + cols - 1) / cols;
   }
-  int rc = tiled ? nvl_tile_launch(x, weight, workspace, m, n, k, EPI_PARTIAL, p.split, stream)
-                 : dispatch_wide<EPI_PARTIAL>(q, x, weight, workspace, m, n, k, s);
+  int rc = dispatch_wide<EPI_PARTIAL>(q, x, weight, workspace, m, n, k, s);
   if (rc != NVL_OK) return rc;
   const int out_cols = mode == EPI_SILU ? n / 2 : n;
   const int64_t quads = m * (int64_t)(out_cols / 4);

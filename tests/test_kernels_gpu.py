@@ -260,24 +260,6 @@ def test_linear_wide_forced_plans_agree(ops, monkeypatch):
     ops._wide_cache.clear()
 
 
-def test_linear_wide_tiled_form_in_its_own_process():
-    """The TILED form of nvl_linear_wide (csrc/gemm_tile.hip: both operands through LDS by LDS-DMA, 8 waves on the
-    matrix pipe) on every shape family and row count it covers, forced on with NVL_WIDE_TILE=1 in a process of its own
-    (the switch is read once): bf16 / SiLU / slab outputs against the fp32 product at the streaming form's bars, ragged
-    last workgroups, K splits, and agreement with the streaming form on row-major weights (tools/gemm_tile_check.py)."""
-    import json
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, NVL_WIDE_TILE="1")
-    cp = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_tile_check.py")], capture_output=True, text=True,
-                        env=env, timeout=900)
-    lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
-    assert lines, cp.stderr[-2000:]
-    res = json.loads(lines[-1])
-    assert cp.returncode == 0 and not res["bad"], res
-
-
 def test_linear_wide_unsupported_shapes_are_reported(ops):
     assert ops.linear_wide_plan(16, 4096, 1000, ops.LINEAR_BF16) is None       # K not a multiple of 128
     assert ops.linear_wide_plan(16, 4100, 1024, ops.LINEAR_BF16) is None       # N not a multiple of 16
