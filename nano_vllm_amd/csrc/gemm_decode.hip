@@ -311,6 +311,9 @@ bool make_plan(int64_t m, int n, int k, int mode, Plan* p) {
   p->nt = nt;
   p->mgroups = mgroups;
   p->mt = (mtiles + mgroups - 1) / mgroups;
+  // one column tile per workgroup exists for <= 3 row tiles (where it is the rule's pick); an ODD number of column tiles
+  // with more rows is reported as not covered (no model shape: the caller's next kernel takes it)
+  if (nt == 1 && p->mt > 3) return false;
   if (p->mt > 16 || (mgroups - 1) * p->mt >= mtiles) return false;   // 16 row tiles are instantiated; no empty row group
   return true;
 }
@@ -342,10 +345,12 @@ int dispatch_mt(const void* x, const void* w, void* out, int64_t m, int n, int k
 #define NVL_MT_CASE(V) \
   case V:              \
     return launch<V, KB, NT, EPI>(x, w, out, m, n, k, p, s);
-  switch (p.mt) {
-    NVL_MT_CASE(1) NVL_MT_CASE(2) NVL_MT_CASE(3) NVL_MT_CASE(4) NVL_MT_CASE(5) NVL_MT_CASE(6) NVL_MT_CASE(7)
-    NVL_MT_CASE(8) NVL_MT_CASE(9) NVL_MT_CASE(10) NVL_MT_CASE(11) NVL_MT_CASE(12) NVL_MT_CASE(13) NVL_MT_CASE(14)
-    NVL_MT_CASE(15) NVL_MT_CASE(16)
+  switch (p.mt) { NVL_MT_CASE(1) NVL_MT_CASE(2) NVL_MT_CASE(3) }
+  if constexpr (NT == 2) {      // one column tile per workgroup is the plan of <= 3 row tiles only (make_plan)
+    switch (p.mt) {
+      NVL_MT_CASE(4) NVL_MT_CASE(5) NVL_MT_CASE(6) NVL_MT_CASE(7) NVL_MT_CASE(8) NVL_MT_CASE(9) NVL_MT_CASE(10)
+      NVL_MT_CASE(11) NVL_MT_CASE(12) NVL_MT_CASE(13) NVL_MT_CASE(14) NVL_MT_CASE(15) NVL_MT_CASE(16)
+    }
   }
 #undef NVL_MT_CASE
   nvl_set_error("nvl_linear_decode: internal plan error (mt=%d nt=%d)", p.mt, NT);

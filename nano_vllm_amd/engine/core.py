@@ -19,6 +19,13 @@ from .seq import Sequence
 
 def _worker_main(config, rank, env):
     os.environ.update(env)                 # NVL_TP_* switches of the parent (spawn does not copy later changes)
+    if os.environ.get("NVL_TP_SHARE_GPU") == "1" and "HSA_CU_MASK" not in os.environ:
+        # functional mode, every rank on GPU 0: give each WORKER its own slice of the compute units (read when the HSA
+        # runtime starts in this fresh process). Ranks whose spinning collective kernels share CUs starve each other on a
+        # time-shared GPU (profiles/r05_tp2_cu_mask_experiment.json: 0 of 16 runs stall with disjoint slices, 4 of 6
+        # without); rank 0's runtime is already up and keeps the whole chip.
+        per = 256 // config.tensor_parallel_size
+        os.environ["HSA_CU_MASK"] = f"0:{rank * per}-{(rank + 1) * per - 1}"
     from .runner import ModelRunner
     ModelRunner(config, rank)              # never returns until "exit" (runner.loop)
 

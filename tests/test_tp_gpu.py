@@ -30,6 +30,11 @@ def _free_port():
 # kernels: nvl_allreduce_run / _add_rmsnorm / _gather between W processes
 def _comm_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
+    # every rank on its own slice of the ONE GPU's compute units (read when the HSA runtime starts, i.e. before the first
+    # device call of this fresh process): ranks whose spinning collective kernels share CUs starve each other
+    # (profiles/r05_tp2_cu_mask_experiment.json) — with disjoint slices the sweep runs at the speed of its kernels
+    per = 256 // world
+    os.environ["HSA_CU_MASK"] = f"0:{rank * per}-{(rank + 1) * per - 1}"
     import torch.distributed as dist
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", f"tcp://127.0.0.1:{port}", world_size=world, rank=rank)
