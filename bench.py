@@ -24,7 +24,7 @@ driver's fields it carries
                  a hipGraph of their own and the events bracket its replay. The rocprofv3
                  kernel-trace summary of this command is in profiles/.
   cpu_baseline : the CPU oracle (oracle/engine.py, a port of the reference's path) timed on this
-                 box's host cores on a bounded sample of the same seeded workload (first 16 sequences).
+                 box's host cores on a bounded sample of the same seeded workload (first 8 sequences x 9 tokens).
   parity       : the engine's own T = 0.6 tokens on that sample, judged exactly against the oracle's
                  race keys with the draws replayed (a by-product of the cpu_baseline leg: the timed
                  oracle pass is teacher-forced with the engine's tokens).
@@ -164,27 +164,16 @@ def main():
                 result["tp_qwen3_32b"] = extra
     with_extras = (world == 1 and tp == 1 and not args.no_extra_configs and args.model == "qwen3-0.6b"
                    and args.workload == "bench" and args.num_seqs == 256 and args.kv_cache_dtype == "bf16")
-    cpu_thread = None
-
-    def start_cpu_baseline():
-        # The CPU baseline is host work (the oracle on <= 64 threads) and the headline engine has already exited: it runs
-        # on a thread WHILE the Qwen3-32B extras use the GPU — their steps are tens of milliseconds of GPU work, which a busy
-        # host does not slow down (measured: the short-step extras, started beside it, ran at HALF speed; they go first).
-        nonlocal cpu_thread
-        if pending_cpu is not None and cpu_thread is None:
-            import threading
-            cpu_thread = threading.Thread(target=pending_cpu, name="cpu_baseline")
-            cpu_thread.start()
-
+    if pending_cpu is not None:
+        # (sequential on purpose: run on a thread beside the extras' child engines, the oracle's 64 host threads slowed
+        #  every one of them — the short-step ones by half, Qwen3-32B by a quarter. Hence the small sample.)
+        pending_cpu()
     if with_extras:
         # The headline is SAFE before any extra starts: the complete line (without `extra_configs`) goes to stderr and
         # to gpurun_out/bench_headline.json now; stdout still carries exactly ONE JSON line, printed at the end, and
-        # the extras stop when the whole run's wall budget (NVL_BENCH_WALL_BUDGET, default 250 s) is spent.
+        # the extras stop when the whole run's wall budget (NVL_BENCH_WALL_BUDGET, default 290 s) is spent.
         keep_headline(result)
-        result["extra_configs"] = extra_configs(args, torch, before_slow_extras=start_cpu_baseline)
-    start_cpu_baseline()
-    if cpu_thread is not None:
-        cpu_thread.join()
+        result["extra_configs"] = extra_configs(args, torch)
     if rank == 0:
         if "tp_qwen3_32b" in result and isinstance(result["tp_qwen3_32b"], dict):
             attach_tp_scaling(args, torch, result)
@@ -229,9 +218,9 @@ NOTES = {
     "roofline_prefill": "prefill_attn_kernel on the prefill batches of the timed pass (their cu_seqlens, random q/k/v): 4 * Hq * "
                         "128 * causal pairs FLOP / HIP-event time; peak 2.5 PF dense bf16.",
     "cpu_baseline": "the CPU oracle (oracle/engine.py, a port of the reference's path: /root/reference does not exist on the GPU "
-                    "box) on the first 16 sequences of the seeded stream, outputs capped at 17 tokens: one prefill step + 16 "
-                    "decode steps at B = 16, teacher-forced with the engine's tokens of the same sample; it runs on <= 64 host "
-                    "threads while the Qwen3-32B extras use the GPU (the short-step extras run before it starts).",
+                    "box) on the first 8 sequences of the seeded stream, outputs capped at 9 tokens: one prefill step + 8 "
+                    "decode steps at B = 8 (~25-30 s on <= 64 host threads), teacher-forced with the engine's tokens of the "
+                    "same sample; nothing runs beside it.",
     "parity": "this build's engine on that sample at T = 0.6 (hipGraph decode, lookahead on): token == argmax(l/T - log E) on "
               "the oracle's logits wherever the key margin > 2 x floor / T, else within 2 x floor / T of the maximum; E = the "
               "engine's counter-based draw (seed, request, position, column) replayed by oracle/philox.py; floor = SURVEY.md's "
@@ -350,7 +339,8 @@ def with_p2p_fallback(attempt, agree):
     if second is not None:
         second["tp_p2p_attempt"] = {
             "value_invalid": (first or {}).get("value"), "ms_per_step": (first or {}).get("ms_per_step"),
-            "p2p_status": ((first or {}).get("config") or {}).get("p2p_status", "latched on another rank"),
+            "p2p_status": (lambda st: "latched on another rank (rank 0's own communicator was clean)" if st in (None, "ok") else st)(
+                ((first or {}).get("config") or {}).get("p2p_status")),
             "p2p_handoff": ((first or {}).get("config") or {}).get("p2p_handoff"),
             "note": "a P2P collective latched a spin timeout in this attempt; `value` is the re-run with NVL_TP_P2P=0"}
         second["config"]["parallelism"] += " [fallback after a latched P2P spin timeout]"
@@ -385,7 +375,7 @@ def run_tp_external(args, torch, dist, rank, world, tp):
         elapsed, prompts, out_lens = timed_passes(args, torch, dist, llm, world, "nccl", sync_group=False)
         result = base_result(args, tp, 1, world, elapsed, sum(out_lens), llm,
                              f"tp{tp} (one engine, tensor-parallel over {tp} GPUs: xGMI P2P all-reduce "
-                             f"{'on' if llm.model_runner.p2p else 'OFF (process group: RCCL)'})")
+                             f"{'on' if llm.model_runner.p2p else 'OFF (process group: ' + ('RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()) + ')'})")
         from nano_vllm_amd import tp as tp_mod
         result["config"]["p2p_handoff"] = tp_mod.handoff_report()
         latched = False
@@ -458,7 +448,7 @@ def compact_extra(line: dict) -> dict:
     return {k: v for k, v in out.items() if v is not None}
 
 
-def extra_configs(args, torch, before_slow_extras=None) -> dict:
+def extra_configs(args, torch) -> dict:
     """The other BASELINE.json configs next to the headline (config 2), each ONE cold pass of its workload in a child
     `bench.py` process (a fresh engine per model; a failure or time-out of an extra never sinks the headline line). The
     stdout line keeps a compact record per config (`compact_extra`; NOTES["extra_configs"] names the fields); the
@@ -486,11 +476,9 @@ def extra_configs(args, torch, before_slow_extras=None) -> dict:
     per_child = float(os.environ.get("NVL_BENCH_EXTRA_TIMEOUT", "300"))
     # the WHOLE run (engine start, warm-up and timed passes, roofline replay, extras) aims at this wall time; an extra
     # whose turn comes after it is spent is skipped and says so
-    budget = float(os.environ.get("NVL_BENCH_WALL_BUDGET", "250"))
+    budget = float(os.environ.get("NVL_BENCH_WALL_BUDGET", "290"))
     env = dict(os.environ, OMP_NUM_THREADS="8")    # the children's host loops; the CPU baseline owns the other cores
     for name, extra in runs.items():
-        if name == "config4_anchor" and before_slow_extras is not None:
-            before_slow_extras()               # (the runs before this one have millisecond steps: they get the host to themselves)
         t0 = time.perf_counter()
         left = budget - (t0 - BENCH_T0)
         if left < 15:
@@ -786,19 +774,19 @@ def pmc_traffic(alg_bytes_per_launch: float, model: str = "qwen3-0.6b", kernel: 
 def cpu_baseline_prepare(torch, llm, model_name, prompts, out_lens, result: dict):
     """The CPU oracle (a port of the reference's path: oracle/engine.py + oracle/model.py; /root/reference does not
     exist on the GPU box, so the imported reference itself cannot run here) on a bounded sample of the same seeded
-    stream: the FIRST 16 sequences, outputs capped at 17 tokens each => one prefill step + 16 decode
-    steps at B = 16 (~60 s of CPU work), timed separately (a decode-heavy figure like the workload's, not a prefill timing).
+    stream: the FIRST 8 sequences, outputs capped at 9 tokens each => one prefill step + 8 decode steps at B = 8 (~25-30 s
+    of CPU work on 64 threads; SURVEY.md §8d's 16 sequences take 40 s for their prefill alone), timed separately (a decode-heavy figure like the workload's, not a prefill timing).
 
     The same leg yields the line's `parity`: the ENGINE first generates exactly that sample at the bench's own
     temperature 0.6 (a fraction of a second), and the oracle pass that is being timed is TEACHER-FORCED with those
-    tokens — same forward passes, same cost — so every one of the 16 x 17 sampled tokens is judged against the oracle's
+    tokens — same forward passes, same cost — so every one of the 8 x 9 sampled tokens is judged against the oracle's
     race keys `l/0.6 - log E` with the draws replayed (oracle/judge.py; floor = the SURVEY constant 0.0195 x absmax
     instead of a second, eager-rounding oracle pass). The oracle is the checker here, never the thing measured or
     shipped; the judging arithmetic itself (Philox replay, top-2 of the keys) is outside the timed steps.
 
     Two phases: THIS function does what needs the engine (the sample's generation, the weights' host copies) and
-    returns a closure with the CPU work; main() runs the closure after the engine has exited — on a thread, while the
-    extras' child engines use the GPU — and it fills result["cpu_baseline"] / result["parity"]."""
+    returns a closure with the CPU work; main() runs the closure after the engine has exited (the GPU is idle meanwhile;
+    nothing else runs beside it) and it fills result["cpu_baseline"] / result["parity"]."""
     from nano_vllm_amd.weights import parameter_shapes, qwen3_config_dict, synth_tensor
     from nanovllm import SamplingParams
     from oracle.judge import SURVEY_FLOOR_REL, judge_run
@@ -807,7 +795,7 @@ def cpu_baseline_prepare(torch, llm, model_name, prompts, out_lens, result: dict
     weights = {n: synth_tensor(n, s, llm.config.seed, device=dev).cpu() for n, s in parameter_shapes(cfg).items()}
     cores = os.cpu_count() or 1
     threads = min(cores, 64)
-    n_seq, cap, temp = 16, 17, 0.6
+    n_seq, cap, temp = 8, 9, 0.6
     sample_p = prompts[:n_seq]
     sample_o = [min(m, cap) for m in out_lens[:n_seq]]
     seed_ = llm.config.seed
