@@ -171,7 +171,7 @@ def main():
     if with_extras:
         # The headline is SAFE before any extra starts: the complete line (without `extra_configs`) goes to stderr and
         # to gpurun_out/bench_headline.json now; stdout still carries exactly ONE JSON line, printed at the end, and
-        # the extras stop when the whole run's wall budget (NVL_BENCH_WALL_BUDGET, default 290 s) is spent.
+        # an extra that no longer fits the run's wall budget (NVL_BENCH_WALL_BUDGET, default 250 s) is skipped.
         keep_headline(result)
         result["extra_configs"] = extra_configs(args, torch)
     if rank == 0:
@@ -462,31 +462,34 @@ def extra_configs(args, torch) -> dict:
               "--gpu-memory-utilization", str(args.gpu_memory_utilization)]
     # (one untimed warm-up pass where a pass is short — a 1.8 s pass measured cold carries the library GEMM's first-call
     #  set-up of every new prefill shape; the 20-35 s passes of the 32B runs stay cold)
-    runs = {"config3": ["--model", "qwen3-8b", "--workload", "prefix", "--warmup", "1"],
+    # name -> (arguments, seconds the child took on the round's boxes incl. engine start). BASELINE's own configs first,
+    # then the per-rank engines: an extra whose expected time does not fit into what is left of the wall budget is skipped.
+    runs = {"config3": (["--model", "qwen3-8b", "--workload", "prefix", "--warmup", "1"], 13),
             # what ONE rank of the TP = 8 / TP = 4 engine computes, run as a TP = 1 engine: a rank's kernels without any
             # collective => an UPPER BOUND per rank, not a TP measurement
-            "tp8_rank_shape_bench": ["--model", "qwen3-32b-tp8rank", "--tp", "1", "--warmup", "0"],
-            "tp4_rank_shape_bench": ["--model", "qwen3-32b-tp4rank", "--tp", "1", "--warmup", "0"],
+            "tp8_rank_shape_bench": (["--model", "qwen3-32b-tp8rank", "--tp", "1", "--warmup", "0"], 20),
             # BASELINE config 4's single-GPU anchor: Qwen3-32B on the bench workload at TP = 1 — what a later
             # `--gpus N` line's tp_qwen3_32b divides by
-            "config4_anchor": ["--model", "qwen3-32b", "--tp", "1", "--warmup", "0"],
-            "config5": ["--model", "qwen3-32b", "--tp", "1", "--workload", "long", "--max-num-seqs", "16", "--warmup", "0"],
-            "tp8_rank_shape_16k_prompts": ["--model", "qwen3-32b-tp8rank", "--tp", "1", "--workload", "long",
-                                           "--max-num-seqs", "16", "--warmup", "1"]}
+            "config4_anchor": (["--model", "qwen3-32b", "--tp", "1", "--warmup", "0"], 48),
+            "config5": (["--model", "qwen3-32b", "--tp", "1", "--workload", "long", "--max-num-seqs", "16", "--warmup", "0"], 30),
+            "tp4_rank_shape_bench": (["--model", "qwen3-32b-tp4rank", "--tp", "1", "--warmup", "0"], 23),
+            "tp8_rank_shape_16k_prompts": (["--model", "qwen3-32b-tp8rank", "--tp", "1", "--workload", "long",
+                                            "--max-num-seqs", "16", "--warmup", "1"], 44)}
     per_child = float(os.environ.get("NVL_BENCH_EXTRA_TIMEOUT", "300"))
-    # the WHOLE run (engine start, warm-up and timed passes, roofline replay, extras) aims at this wall time; an extra
-    # whose turn comes after it is spent is skipped and says so
-    budget = float(os.environ.get("NVL_BENCH_WALL_BUDGET", "290"))
-    env = dict(os.environ, OMP_NUM_THREADS="8")    # the children's host loops; the CPU baseline owns the other cores
-    for name, extra in runs.items():
+    # the WHOLE run (engine start, warm-up and timed passes, roofline replay, CPU baseline, extras) aims at this wall time:
+    # with the driver's 20 + 5 passes the headline part takes ~140 s, and the four extras that fit are BASELINE's configs
+    # and the TP = 8 rank shape; the default 1 + 1 run has room for all six (profiles/r05_final_bench.json)
+    budget = float(os.environ.get("NVL_BENCH_WALL_BUDGET", "250"))
+    env = dict(os.environ, OMP_NUM_THREADS="8")    # the children's host loops
+    for name, (extra, expected_s) in runs.items():
         t0 = time.perf_counter()
         left = budget - (t0 - BENCH_T0)
-        if left < 15:
-            out[name] = {"error": f"skipped: wall budget {budget:.0f} s spent"}
+        if left < expected_s:
+            out[name] = {"error": f"skipped: needs ~{expected_s} s, {max(left, 0):.0f} s left of the {budget:.0f} s wall budget"}
             continue
         try:
             cp = subprocess.run([sys.executable, os.path.abspath(__file__), *common, *extra], capture_output=True,
-                                text=True, timeout=per_child, env=env)
+                                text=True, timeout=min(per_child, 2.5 * expected_s + 30), env=env)
             lines = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
             if cp.returncode != 0 or not lines:
                 out[name] = {"error": f"child exit code {cp.returncode}", "stderr_tail": cp.stderr[-300:]}
@@ -494,7 +497,7 @@ def extra_configs(args, torch) -> dict:
                 full[name] = json.loads(lines[-1])
                 out[name] = compact_extra(full[name])
         except subprocess.TimeoutExpired:
-            out[name] = {"error": f"timed out after {per_child:.0f} s"}
+            out[name] = {"error": f"timed out after {min(per_child, 2.5 * expected_s + 30):.0f} s"}
         except Exception as ex:  # noqa: BLE001 — a secondary measurement must never sink the bench line
             out[name] = {"error": repr(ex)}
         out[name]["wall"] = round(time.perf_counter() - t0, 1)
