@@ -177,6 +177,23 @@ def test_tiny_model_sampled_parity_through_chunked_prefill_and_preemption(tiny_c
                                                 max_num_seqs=8, max_num_batched_tokens=640), sum(max_tokens))
 
 
+def test_tiny_model_batch_above_256_rows_parity(tiny_ckpt):
+    """The reference's DEFAULT `max_num_seqs` is 512 (config.py:11): 320 concurrent sequences put every decode step in the
+    512-row hipGraph bucket — staging image, per-step attention plan, the GEMMs' row groups (20 row tiles), the sampler and
+    the lookahead's token feed all above the 256 rows the bench workload reaches. Mixed greedy / T = 0.6 rows, judged by the
+    CPU oracle with the draws replayed."""
+    prompts = _prompts(320, 5, 60, 512, seed=71)
+    max_tokens = [6] * 320
+    temps = [0.0 if i % 3 else 0.6 for i in range(320)]
+    outs, rec, nblk = _run_ours(tiny_ckpt, prompts, max_tokens, temperatures=temps, enforce_eager=False, max_model_len=256,
+                                num_kvcache_blocks=400, max_num_seqs=512, seed=5)
+    assert [len(o["token_ids"]) for o in outs] == max_tokens
+    assert sum(1 for r in rec if not r["prefill"] and len(r["tokens"]) == 320) == 5
+    v = _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, temperatures=temps, seed=5, max_num_seqs=512)
+    _check("tiny, 320 concurrent sequences (512-row bucket)", v, 320 * 6)
+    assert v.sampled_rows >= 100 * 6
+
+
 def test_sampling_temperature_runs_and_is_seeded(tiny_ckpt):
     from nano_vllm_amd import LLM, SamplingParams
     prompts = _prompts(4, 5, 100, 512, seed=5)
@@ -343,6 +360,24 @@ def test_config2_shaped_batch_sampled_T06_parity_vs_device_oracle(ckpt_06b):
     v = _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device="cuda", temperatures=temps, seed=0, max_num_seqs=64)
     _check("config-2-shaped batch at T = 0.6 (64 seqs x 33 tokens, 0.6B width)", v, 64 * 33)
     assert v.sampled_rows == 64 * 33
+
+
+def test_full_decode_batch_of_the_bench_at_06b_width_sampled_parity(ckpt_06b):
+    """The bench's decode batch at its FULL width: 256 sequences (short prompts, so that the oracle finishes in seconds),
+    T = 0.6, 6 tokens each => 5 hipGraph decode steps at B = 256 over the full 151,936-column vocabulary — 16 row tiles in
+    the skinny GEMMs, the 256-row sampler, 2,048 (sequence, kv head) segments in the stream-K attention plan. Judged like
+    the 64-sequence case above (device-resident oracle, draws replayed, margin rule)."""
+    from random import Random
+    rnd = Random(3)
+    prompts = [[rnd.randint(0, 10000) for _ in range(rnd.randint(20, 120))] for _ in range(256)]
+    max_tokens, temps = [6] * 256, [0.6] * 256
+    outs, rec, nblk = _run_ours(ckpt_06b, prompts, max_tokens, temperatures=temps, enforce_eager=False,
+                                max_model_len=1024, num_kvcache_blocks=400, max_num_seqs=256, dummy_weights=True, seed=0)
+    assert sum(1 for r in rec if not r["prefill"] and len(r["tokens"]) == 256) == 5
+    cfg, w = _oracle_weights_06b("cuda")
+    v = _judge_run(cfg, w, prompts, max_tokens, rec, nblk, device="cuda", temperatures=temps, seed=0, max_num_seqs=256)
+    _check("full bench decode batch at T = 0.6 (256 seqs x 6 tokens, 0.6B width)", v, 256 * 6)
+    assert v.sampled_rows == 256 * 6
 
 
 def test_config1_example_prompts_eager_exact_tokens(ckpt_06b):
