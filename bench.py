@@ -530,6 +530,7 @@ def run_replica(args, torch, dist, rank, world, tp, backend):
         if rec["on"]:
             st = runner.dstage.np
             rec["ctx_tokens"] += int(st["ctx"][:n].sum())
+            rec["dedup_tokens"] = rec.get("dedup_tokens", 0) + int(st["shp"][0]) * runner.block_size * (n - 1)
             if rec["steps"] % 8 == 0:
                 rec["samples"].append((n, st["ctx"][:n].copy(), st["bt"][:n].copy()))
             rec["steps"] += 1
@@ -668,6 +669,7 @@ def fusion_state(runner) -> dict:
     fixed = 2 + (1 if runner.use_plan else 0) + 1 + 3      # feed_tokens, embedding, [plan], final norm, head + 2 sampler
     return {"qknorm_rope_kvstore_in_attention": fused_attn, "silu_mul_in_gate_up_epilogue": True,
             "splitk_sum_in_add_rmsnorm_prologue": True, "per_step_attention_plan": bool(runner.use_plan),
+            "decode_steps_with_shared_prefix_pass": int(runner.prefix_steps),
             "kernel_launches_per_decode_step": geo["layers"] * per_layer + fixed}
 
 
@@ -677,7 +679,8 @@ def decode_step_roofline(runner, rec, result, prefill_s: float) -> dict:
     the last pass minus its prefill steps (host-timed: a prefill starts on a drained queue and ends in a sync)."""
     geo = runner.geo
     L, hkv = geo["layers"], geo["kv_heads"]
-    kv_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * runner.kv_cache.element_size() * L
+    # (K/V blocks that every row of a step shares — prefix-cache hits taken by the shared-prefix pass — count once)
+    kv_bytes = (rec["ctx_tokens"] - rec.get("dedup_tokens", 0)) * 2 * hkv * 128 * runner.kv_cache.element_size() * L
     # streamed once per step: every layer + the lm_head matrix (the tied embedding table when tie_word_embeddings);
     # the embedding GATHER touches only one row per sequence
     params = sum(p.numel() for n, p in runner.model.named_parameters()
@@ -697,7 +700,7 @@ def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
     geo = runner.geo
     hq, hkv, L = geo["heads"], geo["kv_heads"], geo["layers"]
     r = replay(torch, runner.kv_cache, rec["samples"], hq, hkv, runner.config.max_model_len, runner.decode_ws, fused=True,
-               plan=runner.use_plan)
+               plan=runner.use_plan, shared_blocks_of=runner._prefix_blocks_worth_a_pass if runner.share_prefix else None)
     achieved = r["achieved_GBps"]
     # the kernel nvl_paged_attn_decode_fused dispatches to for this geometry (attn_decode.hip: decode_common)
     G, fp8 = hq // hkv, runner.kv_cache.element_size() == 1
@@ -705,8 +708,16 @@ def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
         kernel = f"decode_mfma8_kernel<fused, {'fp8' if fp8 else 'bf16'} KV, G={G}>"
     else:
         kernel = f"decode_stream_fp8_kernel<{G}, fused>" if fp8 else f"decode_stream_kernel<{G}, fused>"
-    step_bytes = rec["ctx_tokens"] * 2 * hkv * 128 * runner.kv_cache.element_size() * L
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+    step_bytes = (rec["ctx_tokens"] - rec.get("dedup_tokens", 0)) * 2 * hkv * 128 * runner.kv_cache.element_size() * L
+    if r["launches_with_shared_prefix_pass"]:
+        kernel = "decode_prefix_kernel + " + kernel
+    extra = {}
+    if r["launches_with_shared_prefix_pass"]:
+        # the reference's attention reads the shared blocks once per sequence; the bytes credited here are the unique ones
+        extra = {"per_sequence_bytes_per_launch": r["per_sequence_bytes_per_launch"],
+                 "rate_in_per_sequence_bytes_GBps": r["per_sequence_bytes_per_launch"] / r["avg_launch_us"] / 1e3,
+                 "launches_with_shared_prefix_pass": r["launches_with_shared_prefix_pass"]}
+    return {**extra, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
             "traffic": pmc_traffic(r["algorithmic_bytes_per_launch"], model, kernel),
             "kernel": kernel + " + decode_stream_combine_kernel",
             "algorithmic_bytes_per_launch": r["algorithmic_bytes_per_launch"], "avg_launch_us": r["avg_launch_us"],

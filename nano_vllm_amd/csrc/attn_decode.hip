@@ -60,8 +60,9 @@ __device__ __forceinline__ float dot8(const u32x4_t& a, const u32x4_t& b) {
 }
 
 // Inclusive prefix of ceil(len/chunk) into pre[1..B], pre[0] = 0. All 256 threads participate.
+// `skip`: leading tiles of every sequence that are NOT part of its share (the shared-prefix pass takes them).
 __device__ __forceinline__ void chunk_prefix(const int32_t* __restrict__ ctx, int batch, int chunk, int* pre,
-                                             int* wsum) {
+                                             int* wsum, int skip = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int carry = 0;
   if (threadIdx.x == 0) pre[0] = 0;
@@ -70,7 +71,7 @@ __device__ __forceinline__ void chunk_prefix(const int32_t* __restrict__ ctx, in
     int v = 0;
     if (i < batch) {
       const int len = ctx[i];
-      v = len > 0 ? (len + chunk - 1) / chunk : 0;
+      v = len > 0 ? max((len + chunk - 1) / chunk - skip, 0) : 0;
     }
     int s = v;
 #pragma unroll
@@ -106,18 +107,39 @@ constexpr int kMinTilesPerWave = 4;
 // and goes. Later segments of a wave's share need no search at all: they always start at tile 0 of the next
 // (sequence, kv-head) pair, and the tile count of a sequence is ceil(context_len / 32).
 struct PlanHeader {          // 32 bytes, followed by nwaves PlanEntry records
-  int64_t total;             // tiles of the whole step = hkv * sum_b ceil(len_b / 32)
+  int64_t total;             // tiles of the whole step = hkv * sum_b (ceil(len_b / 32) - sh_tiles)
   int64_t per;               // tiles per wave
-  int32_t nwaves, batch, hkv, pad;
+  int32_t nwaves, batch, hkv;
+  int32_t sh_tiles;          // leading tiles of EVERY sequence that the shared-prefix pass computes (0: none)
 };
 struct __attribute__((aligned(16))) PlanEntry { int32_t b, h, t0, nb; };   // first segment of a wave's share (b < 0: none)
 
 __global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restrict__ ctx, int batch, int hkv, int nwaves,
-                                                          PlanHeader* __restrict__ hdr) {
+                                                          PlanHeader* __restrict__ hdr,
+                                                          const int32_t* __restrict__ shared_blocks, int tiles_per_block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int* wsum = reinterpret_cast<int*>(smem_raw);
   int* pre = wsum + kWaves;
-  chunk_prefix(ctx, batch, kTile, pre, wsum);
+  // Shared prefix: the caller says how many leading KV blocks every live sequence has in common. Whatever it says, the
+  // tile that takes a sequence's NEW token stays in that sequence's own share (the stream-K kernel stores the token and
+  // starts its softmax there): sh <= min over live sequences of floor((len - 1) / 32).
+  int sh = 0;
+  if (shared_blocks != nullptr) {
+    __shared__ int smin;
+    if (threadIdx.x == 0) smin = 0x7fffffff;
+    __syncthreads();
+    int lmin = 0x7fffffff;
+    for (int i = threadIdx.x; i < batch; i += 256) {
+      const int len = ctx[i];
+      if (len > 0) lmin = min(lmin, (len - 1) / kTile);
+    }
+    atomicMin(&smin, lmin);
+    __syncthreads();
+    const int want = shared_blocks[0];
+    sh = want > 0 ? min(want * tiles_per_block, smin) : 0;
+    if (smin == 0x7fffffff) sh = 0;                     // no live sequence
+  }
+  chunk_prefix(ctx, batch, kTile, pre, wsum, sh);
   __syncthreads();
   const int64_t total = (int64_t)pre[batch] * hkv;
   int64_t per = (total + nwaves - 1) / nwaves;
@@ -128,7 +150,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restr
     hdr->nwaves = nwaves;
     hdr->batch = batch;
     hdr->hkv = hkv;
-    hdr->pad = 0;
+    hdr->sh_tiles = sh;
   }
   PlanEntry* ent = reinterpret_cast<PlanEntry*>(hdr + 1);
   for (int w = threadIdx.x; w < nwaves; w += 256) {
@@ -694,6 +716,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
 
   const int64_t wid = (int64_t)blockIdx.x * kWaves + wave;
   int64_t total, per;
+  int sh = 0;                // leading tiles of every sequence that belong to the shared-prefix pass (plan only)
   PlanEntry first_seg = {-1, 0, 0, 0};
   if (plan != nullptr) {
     // per-step plan: header + this wave's record, two scalar loads (the addresses are wave-uniform); no LDS prefix,
@@ -704,6 +727,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     const bool plan_ok = plan->nwaves == (int)(gridDim.x * kWaves) && plan->batch == batch && plan->hkv == hkv;
     total = plan_ok ? plan->total : 0;
     per = plan->per;
+    sh = plan->sh_tiles;
     if (plan_ok) first_seg = reinterpret_cast<const PlanEntry*>(plan + 1)[wid];
   } else {
     chunk_prefix(ctx, batch, kTile, pre, wsum);
@@ -746,7 +770,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     int bb = b_ + 1, n = 0;
     while (bb < batch) {
       const int len2 = __builtin_amdgcn_readfirstlane(ctx[bb]);
-      n = len2 > 0 ? (len2 + kTile - 1) / kTile : 0;
+      n = len2 > 0 ? (len2 + kTile - 1) / kTile - sh : 0;
       if (n > 0) break;
       ++bb;
     }
@@ -761,9 +785,10 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   // nothing else happens between the loads.
   constexpr int kTL = KV8 ? kLoads8 : kLoads;
   u32x4_t kd[kTL], vd[kTL];
-  auto tile_block = [&](int bb, int ti) { return block_tables[(int64_t)bb * bt_stride + (ti * kTile) / block_size]; };
+  // (tile indices are relative to the sequence's OWN share: tile ti of the share is tile ti + sh of the sequence)
+  auto tile_block = [&](int bb, int ti) { return block_tables[(int64_t)bb * bt_stride + ((ti + sh) * kTile) / block_size]; };
   auto tile_load = [&](int blk, int hh, int ti) {
-    const int t = ti * kTile;
+    const int t = (ti + sh) * kTile;
     if constexpr (KV8) {
       const int64_t base = (((int64_t)blk * hkv + hh) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
       const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
@@ -902,7 +927,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     const int len_cached = FUSED ? len - 1 : len;
 
     for (int ti = t0; ti < t0 + run; ++ti) {
-      const int t = ti * kTile;
+      const int t = (ti + sh) * kTile;
       // which tile comes next (this segment's, or the first one of the next segment), and its block id: the table
       // lookup is issued HERE so that its round trip hides under the wait for the current tile
       const bool in_seg = ti + 1 < t0 + run;
@@ -1018,12 +1043,244 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Shared-prefix pass (plans built with `shared_prefix_blocks`, nvl_decode_plan). When EVERY live sequence of a step
+// starts with the same `sh` tiles of KV (prefix-cache hits on one system prompt — BASELINE config 3: 256 sequences x a
+// 512-token prompt prefix), those tiles are read once per PACK of 16 / G sequences instead of once per sequence: the 16
+// MFMA columns that carry one sequence's G heads (plus zero padding) in decode_mfma8_kernel carry the heads of 16 / G
+// sequences here — same K / V fragments, same online softmax, every column useful. One workgroup per (pack, kv head);
+// its four waves take a quarter of the prefix tiles each (tile loads one tile ahead, through L2 on purpose: the other
+// packs read the same tiles) and merge lane by lane through LDS. The result is ONE more split partial per (sequence,
+// head) — (m, l, O) in the log2 domain like every other — in the slot the stream-K kernel never writes (slots - 1);
+// decode_stream_combine_kernel folds it in. The stream-K kernel itself starts every sequence at tile `sh` (PlanHeader).
+// The new token's q is needed here as well: FUSED recomputes norm + rotation from the raw qkv row (bit-identical to the
+// stream-K kernel's, same helpers); K / V of the new token are the stream-K kernel's business alone.
+template <bool FUSED, bool KV8, int G, bool SLABS>
+__global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+    const int32_t* __restrict__ block_tables, int64_t bt_stride, const int32_t* __restrict__ ctx,
+    float* __restrict__ part_o, float* __restrict__ part_ml, int batch, int hkv, int block_size, int slots,
+    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan) {
+  static_assert(G == 2 || G == 4 || G == 8, "a pack fills the 16 MFMA columns with 16 / G sequences");
+  constexpr int P = 16 / G;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int sh = plan->sh_tiles;
+  if (sh <= 0 || plan->batch != batch || plan->hkv != hkv) return;          // (workgroup-uniform)
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int sub = lane & 15, rq = lane >> 4;      // prologue view: 16 lanes x 8 dims = one row
+  const int col = lane & 15, quad = lane >> 4;    // MFMA view: one (sequence, head) column per lane
+  const int hq = hkv * G;
+  const int pack = blockIdx.x / hkv, h = blockIdx.x - pack * hkv;
+  const int b0 = pack * P;
+  // the block-table row the prefix tiles are looked up in: the pack's first live sequence (all live rows agree on them)
+  int tb = -1;
+#pragma unroll
+  for (int j = P - 1; j >= 0; --j) {
+    const int bj = b0 + j;
+    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0) tb = bj;
+  }
+  if (tb < 0) return;                                                       // a pack of graph padding
+  unsigned char* k_lds = smem_raw + wave * kMWaveLds;
+  unsigned char* v_lds = k_lds + kTile * kMKRow;
+  int kfrag[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) kfrag[c] = col * kMKRow + (((4 * c + quad) ^ col) << 4);
+  const int vfrag = (4 * quad + (col >> 2)) * kMVRow + (col & 3) * 8;
+
+  // ---- q tile [16 columns][128]: column r = (sequence b0 + r / G, head h G + r % G); rows of dead sequences are zero ----
+  {
+    u32x4_t wq = {0u, 0u, 0u, 0u};
+    if constexpr (FUSED) {
+      if (fa.q_norm_w != nullptr) wq = *reinterpret_cast<const u32x4_t*>(fa.q_norm_w + sub * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = rq + 4 * it;
+      const int seq = b0 + r / G, hd = r % G;
+      const int seq_c = seq < batch ? seq : batch - 1;
+      const int len = ctx[seq_c];
+      const bool live = seq < batch && len > 0;
+      u32x4_t qh;
+      if constexpr (FUSED) {
+        int64_t pos = len > 0 ? len - 1 : 0;
+        pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
+        const RopeRegs rr = load_rope_regs(fa.cos_sin + pos * 128, sub);
+        qh = load_qkv8<SLABS>(q, (int64_t)seq_c * fa.qkv_tok_stride + (h * G + hd) * 128 + sub * 8, fa);
+        qh = norm_rope_head_regs(qh, fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
+      } else {
+        qh = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)seq_c * hq + h * G + hd) * 128 + sub * 8);
+      }
+      if (!live) qh = u32x4_t{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4_t*>(k_lds + r * 256 + sub * 16) = qh;
+    }
+  }
+  bf16x8_t qb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    qb[c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(k_lds + col * 256 + (4 * c + quad) * 16));
+
+  constexpr int kTL = KV8 ? kLoads8 : kLoads;
+  u32x4_t kd[kTL], vd[kTL];
+  auto tile_block = [&](int ti) { return block_tables[(int64_t)tb * bt_stride + (ti * kTile) / block_size]; };
+  auto tile_load = [&](int blk, int ti) {
+    const int t = ti * kTile;
+    if constexpr (KV8) {
+      const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
+      const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
+      const unsigned char* vp = reinterpret_cast<const unsigned char*>(vc) + base;
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i) kd[i] = *reinterpret_cast<const u32x4_t*>(kp + i * 8 * 128);
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i) vd[i] = *reinterpret_cast<const u32x4_t*>(vp + i * 8 * 128);
+    } else {
+      const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
+      const bf16_t* kp = kc + base;
+      const bf16_t* vp = vc + base;
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) kd[i] = *reinterpret_cast<const u32x4_t*>(kp + i * 4 * 128);
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) vd[i] = *reinterpret_cast<const u32x4_t*>(vp + i * 4 * 128);
+    }
+  };
+
+  const int t_begin = (wave * sh) / kWaves, t_end = ((wave + 1) * sh) / kWaves;   // this wave's quarter of the prefix
+  float m_run = kNegBig, l_run = 0.f;
+  f32x4_t oacc[8];
+#pragma unroll
+  for (int db = 0; db < 8; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  if (t_begin < t_end) tile_load(tile_block(t_begin), t_begin);
+  __builtin_amdgcn_sched_barrier(0);
+  for (int ti = t_begin; ti < t_end; ++ti) {
+    const bool has_pf = ti + 1 < t_end;
+    const int pf_blk = has_pf ? tile_block(ti + 1) : 0;
+    if constexpr (KV8) {
+      const int r8 = lane >> 3, c0 = (lane & 7) * 2;
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i) {
+        const int rowi = i * 8 + r8;
+        u32x4_t lo16, hi16;
+        fp8x16_to_bf16(kd[i], &lo16, &hi16);
+        *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((c0 ^ (rowi & 15)) << 4)) = lo16;
+        *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + (((c0 + 1) ^ (rowi & 15)) << 4)) = hi16;
+      }
+#pragma unroll
+      for (int i = 0; i < kLoads8; ++i) {
+        const int rowi = i * 8 + r8;
+        u32x4_t lo16, hi16;
+        fp8x16_to_bf16(vd[i], &lo16, &hi16);
+        *reinterpret_cast<u32x4_t*>(v_lds + rowi * kMVRow + c0 * 16) = lo16;
+        *reinterpret_cast<u32x4_t*>(v_lds + rowi * kMVRow + (c0 + 1) * 16) = hi16;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) {
+        const int rowi = i * 4 + rq;
+        *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((sub ^ (rowi & 15)) << 4)) = kd[i];
+      }
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i)
+        *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (has_pf) tile_load(pf_blk, ti + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S^T, online softmax (every prefix token precedes every live sequence's new token: no masking), O^T ----
+    f32x4_t sacc[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      sacc[hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(k_lds + hf * 16 * kMKRow + kfrag[c]);
+        sacc[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qb[c], sacc[hf], 0, 0, 0);
+      }
+    }
+    float mx = kNegBig;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        sacc[hf][rr] *= scale_log2e;
+        mx = fmaxf(mx, sacc[hf][rr]);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float mn = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - mn);
+    m_run = mn;
+    float psum = 0.f;
+    bf16x8_t pb;
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const float pv = exp2f(sacc[hf][rr] - mn);
+        psum += pv;
+        pb[hf * 4 + rr] = (bf16_t)pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 8; ++db) oacc[db] *= alpha;
+#pragma unroll
+    for (int db = 0; db < 8; ++db) {
+      const unsigned char* p0 = v_lds + vfrag + db * 32;
+      const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
+      const s16x4_t a1 =
+          __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * kMVRow));
+      const s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), pb, oacc[db], 0, 0, 0);
+    }
+  }
+  l_run += __shfl_xor(l_run, 16, 64);
+  l_run += __shfl_xor(l_run, 32, 64);
+
+  // ---- the four quarters merge lane by lane (every wave holds the same (column, dims) per lane): waves 1..3 park
+  //      (O, m, l) in their own LDS region as float[34][64], wave 0 folds them in and writes the partial ----
+  float* mine = reinterpret_cast<float*>(k_lds);
+  if (wave != 0) {
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) mine[(db * 4 + r) * 64 + lane] = oacc[db][r];
+    mine[32 * 64 + lane] = m_run;
+    mine[33 * 64 + lane] = l_run;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 1; w < kWaves; ++w) {
+    const float* other = reinterpret_cast<const float*>(smem_raw + w * kMWaveLds);
+    const float mw = other[32 * 64 + lane], lw = other[33 * 64 + lane];
+    const float mn = fmaxf(m_run, mw);
+    const float fa_ = exp2f(m_run - mn), fb_ = exp2f(mw - mn);
+    m_run = mn;
+    l_run = l_run * fa_ + lw * fb_;
+#pragma unroll
+    for (int db = 0; db < 8; ++db)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) oacc[db][r] = oacc[db][r] * fa_ + other[(db * 4 + r) * 64 + lane] * fb_;
+  }
+  const int seq = b0 + col / G, hd = col % G;
+  if (seq < batch && ctx[seq] > 0) {
+    const int64_t pidx = ((int64_t)seq * hq + h * G + hd) * slots + (slots - 1);
+    float* dst = part_o + pidx * 128 + 4 * quad;
+#pragma unroll
+    for (int db = 0; db < 8; ++db) *reinterpret_cast<f32x4_t*>(dst + 16 * db) = oacc[db];
+    if (quad == 0) {
+      part_ml[pidx * 2] = m_run;
+      part_ml[pidx * 2 + 1] = l_run;
+    }
+  }
+}
+
 __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float* __restrict__ part_o,
                                                                      const float* __restrict__ part_ml,
                                                                      const int* __restrict__ meta,
                                                                      const int32_t* __restrict__ ctx,
                                                                      bf16_t* __restrict__ out, int hq, int hkv,
-                                                                     int slots, float* __restrict__ lse) {
+                                                                     int slots, float* __restrict__ lse,
+                                                                     const PlanHeader* __restrict__ plan,
+                                                                     int prefix_slot) {
   // out[b, head, :] = sum_k 2^(m_k - M) O_k / sum_k 2^(m_k - M) l_k over the (b, h) segment's split partials;
   // zero rows when the sequence is padding. The kernel is pure latency (a few KB per block), so everything a
   // typical segment needs — the count, and the first kSpec (m, l, O) slots — is loaded SPECULATIVELY in one
@@ -1038,6 +1295,11 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
   const float* po = part_o + row * slots * 128;
   const int len = ctx[b];
   const int cnt_raw = meta[b * hkv + head / (hq / hkv)];
+  // the shared-prefix pass's partial (prefix_slot >= 0: the launch belongs to a plan with a shared prefix; whether THIS
+  // step has one is in the plan header) — requested with everything else, folded in last
+  const int ps = prefix_slot >= 0 ? prefix_slot : 0;
+  const float m_p = ml[ps * 2], l_p = ml[ps * 2 + 1], o_p = po[ps * 128 + d];
+  const bool has_pre = prefix_slot >= 0 && plan->sh_tiles > 0;
   float m_s[kSpec], l_s[kSpec], o_s[kSpec];
 #pragma unroll
   for (int c = 0; c < kSpec; ++c) {
@@ -1089,6 +1351,13 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
         den += f * lb[j];
       }
   }
+  if (has_pre && cnt > 0) {
+    const float Mb = fmaxf(M, m_p);
+    const float r = exp2f(M - Mb), f = exp2f(m_p - Mb);
+    num = num * r + f * o_p;
+    den = den * r + f * l_p;
+    M = Mb;
+  }
   out[row * 128 + d] = (bf16_t)(cnt > 0 ? num / den : 0.f);
   // optional log-sum-exp of the scaled scores (natural log; what flash-attn returns as softmax_lse): the scores are
   // kept in the log2 domain here, so LSE = ln 2 * (M + log2 den); -inf for padded rows
@@ -1099,7 +1368,8 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
 // one-kv-head shape of Qwen3-32B per rank at TP = 8 — moves 1.2 us from the main kernel into the split merge, which then
 // has twice the partials: 19.1 + 4.5 -> 18.0 + 5.6 us per launch, nothing on the bench shape.
 // profiles/r04_decode_min_tiles_ab.json)
-inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 2; }
+// (+ 1: the last slot belongs to the shared-prefix pass — decode_prefix_kernel — and is never written by a stream-K wave)
+inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 3; }
 
 // LDS and grid of decode_mfma8_kernel — shared by its launcher and by nvl_decode_plan, whose per-wave records are only
 // valid for the grid they were made for. `prefix_batch`: sequences whose tile prefix the kernel keeps in LDS (0 with a plan).
@@ -1115,29 +1385,32 @@ inline int64_t mfma8_grid(int64_t batch, int hkv, int64_t max_context, bool plan
   return grid < 1 ? 1 : grid;
 }
 
+bool plan_shadow_prefix(const void* plan);      // was `plan` built with a shared prefix? (host-side shadow, below)
+
 template <bool FUSED, bool KV8, int G, bool SLABS>
 int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                           void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
-                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse);
+                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, bool prefix);
 
 // qkv as fp32 split-K slabs (fa.qkv_splits > 0) is an instantiation of its own: the bf16 form keeps its registers
 template <bool FUSED, bool KV8, int G = 8>
 int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                         void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
                         void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse) {
+  const bool prefix = plan != nullptr && plan_shadow_prefix(plan);       // the plan was built with a shared prefix
   if constexpr (FUSED) {
     if (fa.qkv_splits > 0)
       return launch_decode_mfma8_s<FUSED, KV8, G, true>(q, kc, vc, bt, bt_stride, ctx, out, batch, hkv, block_size, max_context,
-                                                        scale, workspace, s, fa, plan, lse);
+                                                        scale, workspace, s, fa, plan, lse, prefix);
   }
   return launch_decode_mfma8_s<FUSED, KV8, G, false>(q, kc, vc, bt, bt_stride, ctx, out, batch, hkv, block_size, max_context,
-                                                     scale, workspace, s, fa, plan, lse);
+                                                     scale, workspace, s, fa, plan, lse, prefix);
 }
 
 template <bool FUSED, bool KV8, int G, bool SLABS>
 int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                           void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
-                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse) {
+                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, bool prefix) {
   const int hq = hkv * G;
   const int slots = stream_slots(max_context);
   float* part_o = (float*)workspace;
@@ -1157,11 +1430,30 @@ int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, 
   }
   NVL_REQUIRE(lds <= 160 * 1024, "nvl_paged_attn_decode: batch=%lld needs %zu B of LDS (> 160 KiB)", (long long)batch, lds);
   const int64_t grid = mfma8_grid(batch, hkv, max_context, plan != nullptr);
+  if (prefix) {
+    // shared-prefix pass first (its partial is in place when the merge runs; it reads q / K / V only, so its order
+    // relative to the stream-K kernel — which appends the new token's K / V behind the prefix — does not matter)
+    static bool pattr_done[NVL_MAX_DEVICES] = {};
+    bool& pattr_set = pattr_done[nvl_device_slot()];
+    if (!pattr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_prefix_kernel<FUSED, KV8, G, SLABS>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kWaves * kMWaveLds) != hipSuccess) {
+        nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the shared-prefix kernel");
+        return NVL_ELAUNCH;
+      }
+      pattr_set = true;
+    }
+    constexpr int P = 16 / G;
+    const int64_t pgrid = ((batch + P - 1) / P) * hkv;
+    hipLaunchKernelGGL((decode_prefix_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)pgrid), dim3(256), kWaves * kMWaveLds, s,
+                       (const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, (int)batch,
+                       hkv, block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan);
+  }
   hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
                      (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
                      block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
-                     meta, ctx, (bf16_t*)out, hq, hkv, slots, lse);
+                     meta, ctx, (bf16_t*)out, hq, hkv, slots, lse, (const PlanHeader*)plan, prefix ? slots - 1 : -1);
   return nvl_check_launch("nvl_paged_attn_decode");
 }
 
@@ -1185,7 +1477,7 @@ int launch_decode_stream_fp8(const void* q, void* kc, void* vc, const int32_t* b
                      (unsigned char*)kc, (unsigned char*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (int)batch, hkv,
                      block_size, slots, scale * 1.4426950408889634f, fa);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
-                     meta, ctx, (bf16_t*)out, hq, hkv, slots, lse);
+                     meta, ctx, (bf16_t*)out, hq, hkv, slots, lse, (const PlanHeader*)nullptr, -1);
   return nvl_check_launch("nvl_paged_attn_decode");
 }
 
@@ -1220,7 +1512,7 @@ int launch_decode_stream(const void* q, void* kc, void* vc, const int32_t* bt, i
                      (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (int)batch, hkv,
                      block_size, slots, scale * 1.4426950408889634f, fa);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
-                     meta, ctx, (bf16_t*)out, hq, hkv, slots, lse);
+                     meta, ctx, (bf16_t*)out, hq, hkv, slots, lse, (const PlanHeader*)nullptr, -1);
   return nvl_check_launch("nvl_paged_attn_decode");
 }
 
@@ -1257,19 +1549,27 @@ bool use_valu_g8() {
 // Host-side shadow of the plans nvl_decode_plan has enqueued (keyed by the plan buffer's address): the attention entry
 // points compare the geometry a plan was built for with the launch they are about to make — a plan is a list of
 // per-wave records for ONE (batch, Hkv, max_context, device) and the kernel indexes it by wave id.
-struct PlanShadow { const void* plan; int64_t batch, max_context; int hkv, dev; };
+struct PlanShadow { const void* plan; int64_t batch, max_context; int hkv, dev; bool prefix; };
 static PlanShadow g_plan_shadow[64];
 static int g_plan_shadow_n = 0, g_plan_shadow_next = 0;
 static std::mutex g_plan_shadow_mu;
 
-static void plan_shadow_put(const void* plan, int64_t batch, int hkv, int64_t max_context) {
+static void plan_shadow_put(const void* plan, int64_t batch, int hkv, int64_t max_context, bool prefix) {
   std::lock_guard<std::mutex> lock(g_plan_shadow_mu);
-  const PlanShadow rec = {plan, batch, max_context, hkv, nvl_device_slot()};
+  const PlanShadow rec = {plan, batch, max_context, hkv, nvl_device_slot(), prefix};
   for (int i = 0; i < g_plan_shadow_n; ++i)
     if (g_plan_shadow[i].plan == plan && g_plan_shadow[i].dev == rec.dev) { g_plan_shadow[i] = rec; return; }
   if (g_plan_shadow_n < 64) { g_plan_shadow[g_plan_shadow_n++] = rec; return; }
   g_plan_shadow[g_plan_shadow_next] = rec;                 // more than 64 live plan buffers: forget the oldest
   g_plan_shadow_next = (g_plan_shadow_next + 1) % 64;
+}
+
+bool plan_shadow_prefix(const void* plan) {
+  std::lock_guard<std::mutex> lock(g_plan_shadow_mu);
+  const int dev = nvl_device_slot();
+  for (int i = 0; i < g_plan_shadow_n; ++i)
+    if (g_plan_shadow[i].plan == plan && g_plan_shadow[i].dev == dev) return g_plan_shadow[i].prefix;
+  return false;
 }
 
 static int plan_shadow_check(const void* plan, int64_t batch, int hkv, int64_t max_context, const char* who) {
@@ -1313,13 +1613,16 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
   NVL_REQUIRE(workspace_bytes >= need, "%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   const FusedArgs none = {};
-  if (fa && fa->qkv_splits > 0) {
+  const bool mfma = (G == 8 && (kv_dtype == NVL_KV_FP8 || !use_valu_g8())) || ((G == 2 || G == 4) && use_mfma_small_g());
+  if (fa && fa->qkv_splits > 0 && !mfma) {
     // fp32 split-K slabs as the qkv input: only the matrix-core kernel's prologue sums them
-    const bool mfma = (G == 8 && (kv_dtype == NVL_KV_FP8 || !use_valu_g8())) || ((G == 2 || G == 4) && use_mfma_small_g());
-    if (!mfma) {
-      nvl_set_error("%s: qkv_splits > 0 needs the matrix-core kernel (Hq/Hkv in {2, 4, 8}; got %d)", who, G);
-      return NVL_EUNSUPPORTED;
-    }
+    nvl_set_error("%s: qkv_splits > 0 needs the matrix-core kernel (Hq/Hkv in {2, 4, 8}; got %d)", who, G);
+    return NVL_EUNSUPPORTED;
+  }
+  if (plan != nullptr && plan_shadow_prefix(plan)) {
+    // a plan with a shared prefix starts every sequence's stream-K share behind it: only the matrix-core kernel knows
+    NVL_REQUIRE(mfma, "%s: a plan with a shared prefix needs the matrix-core kernel (Hq/Hkv in {2, 4, 8}; got %d)", who, G);
+    NVL_REQUIRE(block_size % 128 == 0, "%s: a shared prefix needs block_size %% 128 == 0 (got %d)", who, block_size);
   }
   if (kv_dtype == NVL_KV_FP8) {
 #define NVL_DECODE8_CASE(GG)                                                                                           \
@@ -1457,9 +1760,17 @@ extern "C" size_t nvl_decode_plan_bytes(void) {
 }
 
 extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int num_q_heads, int num_kv_heads,
-                               int64_t max_context, void* plan, size_t plan_bytes, void* stream) {
+                               int64_t max_context, const int32_t* shared_prefix_blocks, int block_size, void* plan,
+                               size_t plan_bytes, void* stream) {
   const char* who = "nvl_decode_plan";
   NVL_REQUIRE(context_lens && plan, "%s: null pointer", who);
+  if (shared_prefix_blocks != nullptr) {
+    const int G = num_kv_heads > 0 ? num_q_heads / num_kv_heads : 0;
+    NVL_REQUIRE((uintptr_t)shared_prefix_blocks % 4 == 0, "%s: shared_prefix_blocks must be 4-byte aligned", who);
+    NVL_REQUIRE(block_size > 0 && block_size % 128 == 0, "%s: a shared prefix needs block_size %% 128 == 0 (got %d)", who, block_size);
+    NVL_REQUIRE((G == 8 && !use_valu_g8()) || ((G == 2 || G == 4) && use_mfma_small_g()),
+                "%s: a shared prefix needs the matrix-core decode kernel (Hq/Hkv in {2, 4, 8}; got %d)", who, G);
+  }
   NVL_REQUIRE((uintptr_t)plan % 16 == 0, "%s: plan must be 16-byte aligned", who);
   NVL_REQUIRE(batch >= 0 && batch <= 32768, "%s: batch=%lld out of range [0, 32768]", who, (long long)batch);
   NVL_REQUIRE(num_kv_heads > 0 && num_q_heads % num_kv_heads == 0, "%s: Hq=%d not a multiple of Hkv=%d", who, num_q_heads, num_kv_heads);
@@ -1479,7 +1790,9 @@ extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int n
     attr_set = true;
   }
   hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, context_lens, (int)batch,
-                     num_kv_heads, nwaves, (PlanHeader*)plan);
-  plan_shadow_put(plan, batch, num_kv_heads, max_context);
-  return nvl_check_launch(who);
+                     num_kv_heads, nwaves, (PlanHeader*)plan, shared_prefix_blocks,
+                     shared_prefix_blocks ? block_size / kTile : 0);
+  const int rc = nvl_check_launch(who);
+  if (rc == NVL_OK) plan_shadow_put(plan, batch, num_kv_heads, max_context, shared_prefix_blocks != nullptr);   // (a failed launch leaves no record)
+  return rc;
 }

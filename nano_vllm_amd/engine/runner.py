@@ -153,6 +153,22 @@ def _align(n: int, a: int = 16) -> int:
     return (n + a - 1) // a * a
 
 
+def shared_prefix_blocks(bt: np.ndarray, lens: np.ndarray, block_size: int) -> int:
+    """Number of leading KV blocks that EVERY row of a decode batch has in common: identical block ids in
+    bt[:, 0 .. k) — what the prefix cache hands out when all requests start with the same tokens
+    (block_manager.py:58-82: a cache hit appends the SAME block id to each sequence's table). Only blocks that lie
+    completely before the newest token of the shortest row count (k <= (min(lens) - 1) // block_size): the block a
+    sequence is still writing is never shared."""
+    n = len(lens)
+    if n < 2:
+        return 0
+    cap = min(int((int(lens.min()) - 1) // block_size), bt.shape[1])
+    if cap <= 0 or bt[0, 0] < 0 or not (bt[1:n, 0] == bt[0, 0]).all():       # (the common case: nothing shared)
+        return 0
+    same = (bt[1:n, :cap] == bt[0, :cap]).all(axis=0)
+    return cap if same.all() else int(np.argmin(same))
+
+
 class _Stage:
     """Fixed-layout staging block: pinned host copy + device copy + typed views of both."""
 
@@ -320,6 +336,7 @@ class ModelRunner:
         if self.world_size > 1 and self.rank == 0 and self.chan is not None:
             self.chan.send(_Channel.OP_EXIT)
         self.graphs = {}
+        self.graphs_px = {}
         torch.cuda.synchronize()
         if self.world_size > 1:
             from .. import tp
@@ -388,7 +405,7 @@ class ModelRunner:
         self.dstage = _Stage([
             ("ids", np.int64, (mb,)), ("pos", np.int64, (mb,)), ("rng", np.uint64, (2,)), ("rkey", np.int64, (mb,)),
             ("slots", np.int32, (mb,)), ("ctx", np.int32, (mb,)), ("temps", np.float32, (mb,)),
-            ("src", np.int32, (mb,)), ("bt", np.int32, (mb, w)),
+            ("src", np.int32, (mb,)), ("shp", np.int32, (4,)), ("bt", np.int32, (mb, w)),
         ], self.device, host_copies=2)
         for image in self.dstage.nps:
             image["slots"][:] = -1
@@ -406,6 +423,7 @@ class ModelRunner:
             ("temps", np.float32, (ns,)), ("bt", np.int32, (ns, w)),
         ], self.device)
         self.step_count = 0
+        self.share_prefix = False            # (decided below, once the device side exists)
         self._inflight: list = []            # decode steps enqueued and not yet collected (at most two)
         self._flight_parity = 0
         self._last_rows: dict = {}
@@ -422,6 +440,18 @@ class ModelRunner:
         # its own schedule again (A/B measurements)
         self.use_plan = os.environ.get("NVL_DECODE_PLAN", "1") != "0"
         self.decode_plan = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
+        # shared-prefix attention pass (include/nvl.h, nvl_decode_plan): a decode step whose sequences all start with the
+        # same KV blocks (prefix-cache hits on one system prompt) reads them once per pack of 16 / G sequences. It is one
+        # more launch per layer, so a step takes it only when the K/V bytes it saves are worth that (prepare_decode);
+        # the graph of a bucket WITH the pass is captured the first time a step of that bucket wants it.
+        # NVL_SHARED_PREFIX=0 switches it off; NVL_SHARED_PREFIX_MIN_MB sets the threshold (saved MB per layer).
+        self.share_prefix = (self.use_plan and os.environ.get("NVL_SHARED_PREFIX", "1") != "0"
+                             and ops.decode_attention_shares_prefixes(self.geo["heads"], self.geo["kv_heads"],
+                                                                      self.block_size))
+        self.share_prefix_min_bytes = float(os.environ.get("NVL_SHARED_PREFIX_MIN_MB", "32")) * 1e6
+        self.decode_plan_px = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
+        self.graphs_px: dict[int, torch.cuda.CUDAGraph] = {}
+        self.prefix_steps = 0                # decode steps that ran the shared-prefix pass (reporting)
         self._step_done = [torch.cuda.Event(), torch.cuda.Event()]
 
     # ------------------------------------------------------------------ warm-up + KV cache
@@ -556,6 +586,7 @@ class ModelRunner:
             bt[i, :len(t)] = t
             bt[i, len(t):] = -1
         key[:n, 0], key[:n, 1], key[:n, 2] = ids, nblk, gen
+        st["shp"][0] = self._prefix_blocks_worth_a_pass(bt, lens, n) if self.share_prefix else 0
         # neutralise rows used by a previous, larger batch (graph padding: slot -1, context 0)
         dirty = self._dirty[self.dstage.cur]
         if dirty > n:
@@ -564,6 +595,17 @@ class ModelRunner:
             key[n:dirty] = -1
         self._dirty[self.dstage.cur] = n
         return n
+
+    def _prefix_blocks_worth_a_pass(self, bt: np.ndarray, lens: np.ndarray, n: int) -> int:
+        """Shared leading blocks of the batch, or 0 when the K/V bytes the shared-prefix pass would save per layer
+        (the blocks are read once per pack of 16 / G sequences instead of once per sequence) do not pay for its launch."""
+        k = shared_prefix_blocks(bt[:n], lens, self.block_size)
+        if k == 0:
+            return 0
+        pack = 16 // (self.geo["heads"] // self.geo["kv_heads"])
+        esize = 1 if self.config.kv_cache_dtype == "fp8" else 2
+        saved = k * self.block_size * (n - -(-n // pack)) * self.geo["kv_heads"] * 2 * 128 * esize
+        return k if saved >= self.share_prefix_min_bytes else 0
 
     # ------------------------------------------------------------------ forward
     def _next_rng(self, st: _Stage) -> None:
@@ -583,11 +625,13 @@ class ModelRunner:
             logits = self.model.compute_logits_shard(hidden)
             sampler.forward_shard(logits, temps, col0, out, offset_dev=rng, row_keys=rkey)
 
-    def _decode_rows(self, r0: int, r1: int, ws, sampler, plan=None):
-        """Decode forward for rows [r0, r1) of the static device buffers, on the current stream."""
+    def _decode_rows(self, r0: int, r1: int, ws, sampler, plan=None, prefix: bool = False):
+        """Decode forward for rows [r0, r1) of the static device buffers, on the current stream. `prefix`: the plan
+        carries the step's shared-prefix block count (staged as `shp`), the attention launches run the shared pass."""
         t = self.dstage.t
         if plan is not None:
-            ops.decode_plan(t["ctx"][r0:r1], self.geo["heads"], self.geo["kv_heads"], self.config.max_model_len, plan)
+            ops.decode_plan(t["ctx"][r0:r1], self.geo["heads"], self.geo["kv_heads"], self.config.max_model_len, plan,
+                            shared_prefix_blocks=t["shp"][:1] if prefix else None, block_size=self.block_size)
         set_context(False, slot_mapping=t["slots"][r0:r1], context_lens=t["ctx"][r0:r1],
                     block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len,
                     decode_plan=plan)
@@ -596,7 +640,7 @@ class ModelRunner:
         reset_context()
 
     @torch.inference_mode()
-    def _forward_decode(self, bs: int):
+    def _forward_decode(self, bs: int, prefix: bool = False):
         """Decode forward on the static device buffers (captured per bucket, or run eagerly): layers + lm_head
         + sampler, at any TP degree (the reference captures the layers only and runs lm_head, the logits
         gather and the sampler eagerly, model_runner.py:212,218). (A micro-batched form — two half-batch chains on
@@ -605,17 +649,24 @@ class ModelRunner:
         # input ids of sequences that were in the previous decode step come straight from its sampled ids
         t = self.dstage.t
         ops.feed_tokens(t["ids"][:bs], t["src"][:bs], self.tokens_dev)
-        self._decode_rows(0, bs, self.decode_ws, self.sampler, self.decode_plan if self.use_plan else None)
+        plan = (self.decode_plan_px if prefix else self.decode_plan) if self.use_plan else None
+        self._decode_rows(0, bs, self.decode_ws, self.sampler, plan, prefix)
 
     @torch.inference_mode()
     def _launch_decode(self, n: int) -> None:
         """Every rank: upload the current image, run the step, start the D2H of the ids (rank 0)."""
         self.dstage.upload()
         bucket = next((b for b in self.graph_bs if b >= n), None) if self.graphs else None
-        if bucket is not None:
+        prefix = self.share_prefix and int(self.dstage.np["shp"][0]) > 0       # (every rank reads the same image)
+        self.prefix_steps += int(prefix)
+        if bucket is not None and prefix:
+            if bucket not in self.graphs_px:
+                self._capture_prefix_graph(bucket)
+            self.graphs_px[bucket].replay()
+        elif bucket is not None:
             self.graphs[bucket].replay()
         else:
-            self._forward_decode(n)
+            self._forward_decode(n, prefix)
         host = self.tokens_host if self._flight_parity == 0 else self.tokens_host_b
         done = self._step_done[self._flight_parity]
         if self.rank == 0:
@@ -703,7 +754,23 @@ class ModelRunner:
             if pool is None:
                 pool = graph.pool()
             self.graphs[bs] = graph
+        if self.share_prefix:
+            # one eager step WITH the shared-prefix pass on the neutral inputs (every row is padding: the pass finds
+            # nothing to do): its kernel's LDS reservation is made here, outside any capture
+            self._forward_decode(self.graph_bs[0], prefix=True)
         torch.cuda.synchronize()
         from .. import layers
         layers.release_tuning_scratch()                 # the decode-GEMM choices of every bucket are made by now
         self.graph_pool = pool
+
+    @torch.inference_mode()
+    def _capture_prefix_graph(self, bs: int) -> None:
+        """The decode graph of bucket `bs` WITH the shared-prefix attention pass, captured the first time a step wants
+        it (most workloads never do). No warm-up run: the static buffers hold a real step's inputs by now, and every
+        choice the launches make was made when the bucket's plain graph was captured. Every rank captures at the same
+        step (the decision is read from the staged image)."""
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, self.graph_pool):
+            self._forward_decode(bs, prefix=True)
+        self.graphs_px[bs] = graph

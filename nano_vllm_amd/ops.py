@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnvl_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # name -> (restype, argtypes); mirrors include/nvl.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -45,7 +45,7 @@ SIGNATURES = {
                                       c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int,
                                       c_void_p, c_void_p, c_void_p]),
     "nvl_decode_plan_bytes": (c_size_t, []),
-    "nvl_decode_plan": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_size_t, c_void_p]),
+    "nvl_decode_plan": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
     "nvl_paged_attn_decode_fused": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p,
                                             c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                             c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int, c_void_p,
@@ -337,16 +337,28 @@ def decode_plan_bytes() -> int:
 
 
 def decode_plan(context_lens: torch.Tensor, num_q_heads: int, num_kv_heads: int, max_context: int,
-                plan: torch.Tensor | None = None) -> torch.Tensor:
+                plan: torch.Tensor | None = None, shared_prefix_blocks: torch.Tensor | None = None,
+                block_size: int = 256) -> torch.Tensor:
     """Per-step work plan of the decode attention launches (same for every layer of the step): `plan` is a uint8
-    device buffer of decode_plan_bytes() bytes, allocated when None."""
+    device buffer of decode_plan_bytes() bytes, allocated when None. `shared_prefix_blocks`: int32 device tensor whose
+    first element is the number of leading KV blocks every live sequence has in common — the attention calls that
+    consume this plan then run the shared-prefix pass (include/nvl.h)."""
     _dev(context_lens, "context_lens")
     assert context_lens.dtype == torch.int32 and context_lens.is_contiguous()
     if plan is None:
         plan = torch.empty(decode_plan_bytes(), dtype=torch.uint8, device=context_lens.device)
+    shp = None
+    if shared_prefix_blocks is not None:
+        assert shared_prefix_blocks.dtype == torch.int32 and shared_prefix_blocks.device == context_lens.device
+        shp = shared_prefix_blocks.data_ptr()
     _check(lib().nvl_decode_plan(context_lens.data_ptr(), context_lens.numel(), num_q_heads, num_kv_heads, max_context,
-                                 plan.data_ptr(), plan.numel(), _stream()))
+                                 shp, block_size, plan.data_ptr(), plan.numel(), _stream()))
     return plan
+
+
+def decode_attention_shares_prefixes(num_q_heads: int, num_kv_heads: int, block_size: int) -> bool:
+    """Can a decode plan carry a shared prefix for this geometry? (matrix-core kernel, 128-token-aligned blocks)"""
+    return block_size % 128 == 0 and decode_attention_takes_qkv_slabs(num_q_heads, num_kv_heads)
 
 
 def _lse_ptr(lse: torch.Tensor | None, shape: tuple) -> int | None:

@@ -19,8 +19,9 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run_ours(path, prompts, max_tokens, capture_logits=False, temperatures=None, **kw):
-    """`temperatures` (per prompt; None = greedy). The engine's draw seed is `kw["seed"]` (Config.seed, default 0)."""
+def _run_ours(path, prompts, max_tokens, capture_logits=False, temperatures=None, info=None, **kw):
+    """`temperatures` (per prompt; None = greedy). The engine's draw seed is `kw["seed"]` (Config.seed, default 0).
+    `info` (dict): receives the runner's counters before the engine is torn down."""
     from nano_vllm_amd import LLM, SamplingParams
     llm = LLM(path, **kw)
     rec = []
@@ -57,6 +58,8 @@ def _run_ours(path, prompts, max_tokens, capture_logits=False, temperatures=None
     outs = llm.generate(prompts, sps, use_tqdm=False)
     nblk = llm.config.num_kvcache_blocks
     runner.call = orig
+    if info is not None:
+        info.update(prefix_steps=runner.prefix_steps, prefix_graphs=sorted(runner.graphs_px))
     llm.exit()
     if capture_logits:
         assert len(logits_log) == len(rec)
@@ -192,6 +195,52 @@ def test_tiny_model_batch_above_256_rows_parity(tiny_ckpt):
     v = _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, temperatures=temps, seed=5, max_num_seqs=512)
     _check("tiny, 320 concurrent sequences (512-row bucket)", v, 320 * 6)
     assert v.sampled_rows >= 100 * 6
+
+
+@pytest.mark.parametrize("eager", [True, False])
+def test_sequences_that_end_exactly_on_max_model_len_and_on_block_edges(tiny_ckpt, eager):
+    """Edges of the paged layout end to end: a sequence whose last token fills `max_model_len` exactly (the widest block
+    table the staging image carries: prompt 500 + 12 = 512 = two full blocks), one that ends exactly on a block edge (255 +
+    1), one whose only generated tokens open a fresh block (256 + 2), a one-token prompt, and `max_tokens = 1` (the token
+    comes from the prefill step alone)."""
+    g = torch.Generator().manual_seed(83)
+    lens, max_tokens = [500, 255, 256, 1, 511, 257], [12, 1, 2, 9, 1, 255]
+    prompts = [torch.randint(0, 512, (n,), generator=g).tolist() for n in lens]
+    outs, rec, nblk = _run_ours(tiny_ckpt, prompts, max_tokens, enforce_eager=eager, max_model_len=512,
+                                num_kvcache_blocks=16, max_num_seqs=8)
+    assert [len(o["token_ids"]) for o in outs] == max_tokens
+    _check(f"block / max_model_len edges eager={eager}", _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, max_num_seqs=8),
+           sum(max_tokens))
+
+
+@pytest.mark.parametrize("name,eager", [("qwen3-tiny", True), ("qwen3-tiny", False), ("qwen3-tiny-untied", False),
+                                        ("qwen3-tiny-g8", False)])
+def test_shared_system_prompt_runs_the_shared_prefix_attention_pass(name, eager, monkeypatch):
+    """BASELINE config 3 in small: nine requests start with the same 530 tokens (two full KV blocks come out of the
+    prefix cache with the SAME block ids, block_manager.py:58-82) and one request has nothing in common with them. While
+    that one is alive the decode steps are plain; once it has finished every live row shares two blocks and the steps
+    take the shared-prefix pass (forced on for these tiny shapes: NVL_SHARED_PREFIX_MIN_MB=0) — in graph mode through
+    graphs captured at that moment, for every bucket the shrinking batch passes through. Tokens, batches and block
+    tables are judged against the oracle engine as in every other test here; greedy and sampled rows in one batch."""
+    from nano_vllm_amd.weights import write_synthetic_checkpoint
+    monkeypatch.setenv("NVL_SHARED_PREFIX_MIN_MB", "0")
+    path = tempfile.mkdtemp(prefix=name.replace("-", "_") + "_px_")
+    write_synthetic_checkpoint(path, name, seed=2, vocab_size=512, max_position_embeddings=2048)
+    g = torch.Generator().manual_seed(97)
+    shared = torch.randint(0, 512, (530,), generator=g).tolist()
+    prompts = [shared + torch.randint(0, 512, (int(n),), generator=g).tolist() for n in (1, 30, 200, 77, 5, 250, 13, 300, 64)]
+    prompts.insert(3, torch.randint(0, 512, (700,), generator=g).tolist())
+    max_tokens = [40, 22, 31, 6, 40, 17, 40, 9, 28, 35]
+    temps = [0.0, 0.7, 0.0, 0.0, 0.6, 0.0, 0.0, 1.0, 0.0, 0.0]
+    info = {}
+    outs, rec, nblk = _run_ours(path, prompts, max_tokens, temperatures=temps, info=info, enforce_eager=eager,
+                                max_model_len=2048, num_kvcache_blocks=40, max_num_seqs=16, seed=5)
+    assert [len(o["token_ids"]) for o in outs] == max_tokens
+    decode_steps = sum(1 for r in rec if not r["prefill"])
+    assert 0 < info["prefix_steps"] < decode_steps, (info, decode_steps)
+    assert eager or len(info["prefix_graphs"]) >= 1
+    _check(f"shared system prompt {name} eager={eager}",
+           _judge(path, prompts, max_tokens, rec, nblk, temperatures=temps, seed=5, max_num_seqs=16), sum(max_tokens))
 
 
 def test_sampling_temperature_runs_and_is_seeded(tiny_ckpt):

@@ -87,6 +87,14 @@ class FakeRunner(ModelRunner):
             assert (row[len(s.block_table):] == -1).all()
             self.checked_rows += 1
         assert (st["ctx"][n:self.max_bs] == 0).all() and (st["slots"][n:self.max_bs] == -1).all()
+        # shared-prefix block count of the step (0 unless the pass is switched on): against a direct count on the sequences
+        want = 0
+        if self.share_prefix and n >= 2:
+            cap = (min(s.num_tokens for s in seqs) - 1) // bs
+            while want < cap and all(s.block_table[want] == seqs[0].block_table[want] for s in seqs):
+                want += 1
+        assert st["shp"][0] == want, (int(st["shp"][0]), want)
+        self.shared_seen = max(getattr(self, "shared_seen", 0), want)
         toks = _next_token(ids, st["pos"][:n], st["rkey"][:n])
         self.tokens[:n] = toks
         self._inflight.append((n, toks.copy()))
@@ -165,6 +173,56 @@ def test_lookahead_equals_serial_with_more_prompts_than_rows(seed):
     assert out_a == out_b
     assert [len(t) for t in out_a] == [sp.max_tokens for sp in sps]
     assert a.model_runner.checked_rows > 0
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_staged_shared_prefix_block_count(seed):
+    """Requests that start with the same tokens get the same leading block ids from the prefix cache
+    (block_manager.py:58-82); every staged decode image carries how many leading blocks ALL its rows share (checked in
+    FakeRunner._launch_decode against a direct count) — 0 while a request without the prefix is in the batch, and never
+    the block a row is still writing. The same workload generates the same tokens with the count switched off."""
+    r = Random(seed)
+    bs = 256
+    common = [r.randint(0, VOCAB - 1) for _ in range(2 * bs + 17)]
+    prompts = [common + [r.randint(0, VOCAB - 1) for _ in range(r.randint(0, 300))] for _ in range(7)]
+    prompts.insert(2, [r.randint(0, VOCAB - 1) for _ in range(40)])
+    prompts.append(common[:2 * bs])              # ends exactly on the shared blocks' edge: its newest token opens block 2
+    sps = [SamplingParams(temperature=0.0, ignore_eos=True, max_tokens=m) for m in (9, 30, 4, 12, 25, 300, 7, 18, 11)]
+    kw = dict(max_num_seqs=8, max_model_len=2048, num_kvcache_blocks=40, max_num_batched_tokens=1024)
+    outs = []
+    for on in (True, False):
+        eng = _engine(True, **kw)
+        eng.model_runner.share_prefix = on
+        eng.model_runner.share_prefix_min_bytes = 0.0
+        outs.append(_generate(eng, prompts, sps))
+        assert eng.model_runner.shared_seen == (2 if on else 0)
+    assert outs[0] == outs[1]
+
+
+def test_shared_prefix_blocks_helper_and_the_launch_threshold():
+    from nano_vllm_amd.engine.runner import shared_prefix_blocks
+    bt = np.full((5, 8), -1, dtype=np.int32)
+    bt[:, :3] = [7, 9, 4]
+    bt[:, 3] = [10, 11, 12, 13, 14]
+    lens = np.array([900, 800, 1000, 770, 1024])
+    assert shared_prefix_blocks(bt, lens, 256) == 3
+    assert shared_prefix_blocks(bt, np.array([900, 800, 1000, 769, 1024]), 256) == 3      # (769 - 1) // 256 = 3
+    assert shared_prefix_blocks(bt, np.array([900, 800, 1000, 768, 1024]), 256) == 2      # block 2 holds that row's newest token
+    assert shared_prefix_blocks(bt[:1], lens[:1], 256) == 0                                  # one row shares with nobody
+    bt2 = bt.copy()
+    bt2[3, 1] = 99
+    assert shared_prefix_blocks(bt2, lens, 256) == 1
+    bt2[4, 0] = 98
+    assert shared_prefix_blocks(bt2, lens, 256) == 0
+    assert shared_prefix_blocks(np.full((4, 8), -1, dtype=np.int32), np.array([300] * 4), 256) == 0   # empty tables
+    # the threshold: K/V bytes saved per layer = blocks x 256 tokens x (rows - packs) x Hkv x 2 x 128 x 2 B
+    eng = _engine(True, max_num_seqs=8, max_model_len=2048, num_kvcache_blocks=40)
+    run = eng.model_runner                       # geometry: 4 query heads, 2 kv heads => packs of 8 rows
+    saved = 3 * 256 * (5 - 1) * 2 * 2 * 128 * 2
+    run.share_prefix_min_bytes = saved
+    assert run._prefix_blocks_worth_a_pass(bt, lens, 5) == 3
+    run.share_prefix_min_bytes = saved + 1
+    assert run._prefix_blocks_worth_a_pass(bt, lens, 5) == 0
 
 
 @pytest.mark.parametrize("seed", range(6))

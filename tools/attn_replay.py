@@ -67,12 +67,17 @@ def bench_decode_batches(num_seqs: int = 256, num_blocks: int = 9380, every: int
 
 
 def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: int = 2, fused: bool = False,
-           plan: bool = True, graph: bool = True):
+           plan: bool = True, graph: bool = True, shared_blocks_of=None):
     """Time nvl_paged_attn_decode (main kernel + split combine) on the recorded batches.
     kv_cache: [2, L, num_blocks, Hkv, block, 128]. Block ids are folded into the cache with a
     modulo when the cache is smaller than the pool the schedule was recorded with.
     plan: as the engine does, one nvl_decode_plan per batch (outside the timed bracket: it is one ~4 us launch per
-    STEP, not per layer) shared by the L layer launches."""
+    STEP, not per layer) shared by the L layer launches.
+    shared_blocks_of(bt, lens, n) -> int (the engine's ModelRunner._prefix_blocks_worth_a_pass): batches whose rows all
+    start with the same KV blocks are replayed WITH the shared-prefix pass, as the engine runs them. The bytes such a
+    batch is credited with are the UNIQUE ones — the common blocks once, not once per sequence — so the achieved
+    rate stays a rate of bytes that had to come from HBM; `per_sequence_bytes_per_launch` is the reference's figure
+    (flash_attn_with_kvcache reads every sequence's whole table, layers/attention.py:72-74)."""
     from nano_vllm_amd import ops
     L, nblk = kv_cache.shape[1], kv_cache.shape[2]
     dev = kv_cache.device
@@ -87,14 +92,17 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
         fr = torch.arange(40960, device=dev).float()[:, None] * inv[None]
         table = torch.cat([fr.cos(), fr.sin()], -1).contiguous()
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    total_ms, total_bytes, launches = 0.0, 0, 0
+    total_ms, total_bytes, launches, per_seq_bytes, px_launches = 0.0, 0, 0, 0, 0
+    block_size = kv_cache.shape[4]
     for n, ctx, bt in samples:
         if bt.max() >= nblk:
             bt = np.where(bt >= 0, bt % nblk, bt).astype(np.int32)
         ctx_d = torch.from_numpy(np.ascontiguousarray(ctx)).to(dev)
         bt_d = torch.from_numpy(np.ascontiguousarray(bt)).to(dev)
         q = q_all[:n]
-        step_plan = ops.decode_plan(ctx_d, hq, hkv, max_ctx) if plan else None
+        shared = int(shared_blocks_of(bt, np.asarray(ctx, dtype=np.int64), n)) if (plan and shared_blocks_of) else 0
+        shp = torch.tensor([shared], dtype=torch.int32, device=dev) if shared > 0 else None
+        step_plan = ops.decode_plan(ctx_d, hq, hkv, max_ctx, shared_prefix_blocks=shp, block_size=block_size) if plan else None
 
         def layers():
             for layer in range(L):
@@ -125,9 +133,13 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
             stop.record()
             torch.cuda.synchronize()
         total_ms += start.elapsed_time(stop)
-        total_bytes += int(ctx.sum()) * 2 * hkv * 128 * kv_cache.element_size() * L
+        tok_bytes = 2 * hkv * 128 * kv_cache.element_size() * L
+        per_seq_bytes += int(ctx.sum()) * tok_bytes
+        total_bytes += (int(ctx.sum()) - shared * block_size * (n - 1)) * tok_bytes
         launches += L
+        px_launches += L if shared > 0 else 0
     return dict(achieved_GBps=total_bytes / (total_ms * 1e-3) / 1e9, algorithmic_bytes_per_launch=total_bytes / launches,
+                per_sequence_bytes_per_launch=per_seq_bytes / launches, launches_with_shared_prefix_pass=px_launches,
                 avg_launch_us=total_ms * 1e3 / launches, launches_timed=launches, reps=reps,
                 launched="one captured hipGraph per step (L layer launches), replayed" if graph else "eagerly from Python")
 

@@ -38,6 +38,16 @@ newtests)
 fp8)
   timeout 900 python -m pytest tests -m gpu -q -rf -k "fp8" > $OUT/pytest_fp8.log 2>&1; echo "fp8 tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|fp8 KV vs" $OUT/pytest_fp8.log | tail -12
   timeout 600 python bench.py --kv-cache-dtype fp8 --no-cpu-baseline > $OUT/bench_fp8kv.json 2> $OUT/bench_fp8kv.err; echo "bench fp8 rc=$?"; tail -c 400 $OUT/bench_fp8kv.err; cut -c1-1500 $OUT/bench_fp8kv.json;;
+px)
+  # shared-prefix attention pass: kernel parity, engine parity, config 3 A/B (pass off / on, alternating), headline sanity
+  timeout 400 python -m pytest tests/test_shared_prefix_gpu.py -q -rf > $OUT/pytest_px_kernel.log 2>&1; echo "px kernel rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|Error" $OUT/pytest_px_kernel.log | tail -30
+  timeout 500 python -m pytest tests/test_e2e_gpu.py -q -rf -s -k "shared_system_prompt or block_edges" > $OUT/pytest_px_e2e.log 2>&1; echo "px e2e rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|shared system|block /" $OUT/pytest_px_e2e.log | cut -c1-400 | tail -20
+  for x in 0 1 0 1; do NVL_SHARED_PREFIX=$x timeout 300 python bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $OUT/cfg3_px$x.json 2> $OUT/cfg3_px$x.err; echo "cfg3 px=$x rc=$?"; tail -c 300 $OUT/cfg3_px$x.err; python -c "
+import json,sys
+d=json.loads([l for l in open('$OUT/cfg3_px$x.json') if l.startswith('{')][-1])
+r=d['roofline']; print('px=$x', round(d['value']), 'tok/s', d['ms_per_step'], 'ms; attn', round(r['avg_launch_us'],1), 'us frac', round(r['frac'],3), 'step', d['config']['decode_ms_per_step_by_batch'], 'px steps', d['config']['decode_step_fusions'].get('decode_steps_with_shared_prefix_pass'))
+"; cp $OUT/cfg3_px$x.json $OUT/cfg3_px${x}_run_$(date +%s).json; done
+  timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 2 --warmup 1 > $OUT/headline_quick.json 2> $OUT/headline_quick.err; echo "headline rc=$?"; cut -c1-400 $OUT/headline_quick.json;;
 cfg3)
   timeout 900 python bench.py --model qwen3-8b --workload prefix --no-cpu-baseline --warmup 0 > $OUT/bench_cfg3_8b_prefix.json 2> $OUT/bench_cfg3.err; echo "cfg3 rc=$?"; tail -c 300 $OUT/bench_cfg3.err; cut -c1-1200 $OUT/bench_cfg3_8b_prefix.json;;
 tpfunc)
