@@ -530,7 +530,8 @@ def run_replica(args, torch, dist, rank, world, tp, backend):
         if rec["on"]:
             st = runner.dstage.np
             rec["ctx_tokens"] += int(st["ctx"][:n].sum())
-            rec["dedup_tokens"] = rec.get("dedup_tokens", 0) + int(st["shp"][0]) * runner.block_size * (n - 1)
+            if st["shp"][0] > 0:       # blocks a group of rows shares count once (the shared-prefix pass reads them so)
+                rec["dedup_tokens"] = rec.get("dedup_tokens", 0) + int(st["shp"][0]) * runner.block_size * (int(st["shp"][1:1 + n].sum()) - 1)
             if rec["steps"] % 8 == 0:
                 rec["samples"].append((n, st["ctx"][:n].copy(), st["bt"][:n].copy()))
             rec["steps"] += 1
@@ -700,7 +701,7 @@ def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
     geo = runner.geo
     hq, hkv, L = geo["heads"], geo["kv_heads"], geo["layers"]
     r = replay(torch, runner.kv_cache, rec["samples"], hq, hkv, runner.config.max_model_len, runner.decode_ws, fused=True,
-               plan=runner.use_plan, shared_blocks_of=runner._prefix_blocks_worth_a_pass if runner.share_prefix else None)
+               plan=runner.use_plan, shared_blocks_of=runner._prefix_group_worth_a_pass if runner.share_prefix else None)
     achieved = r["achieved_GBps"]
     # the kernel nvl_paged_attn_decode_fused dispatches to for this geometry (attn_decode.hip: decode_common)
     G, fp8 = hq // hkv, runner.kv_cache.element_size() == 1

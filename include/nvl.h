@@ -233,27 +233,24 @@ int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
  * layers/attention.py:72-74, and each call re-derives its own split
  * schedule). Enqueue-only, graph-capturable; `plan` is caller-owned,
  * nvl_decode_plan_bytes() bytes, 16-byte aligned.
- * shared_prefix_blocks (optional, may be NULL; ABI v5): DEVICE pointer to one
- *   int32 = the number of leading KV blocks that EVERY live sequence of the
- *   step has in common (identical block_tables[b][0 .. n) for all b with
- *   context_lens[b] > 0 — what the reference's prefix cache produces when all
- *   requests start with the same prompt prefix, engine/block_manager.py:58-82).
- *   A plan built with it makes the attention calls that consume it run a
- *   SHARED-PREFIX PASS: those blocks are read once per pack of 16 / (Hq/Hkv)
- *   sequences instead of once per sequence, and the per-sequence kernel
- *   starts behind them; results are merged like any split (same value up to
- *   the fp32 summation order). The value is read on the device when the plan
- *   kernel runs (graph replays see the current value; 0 = no shared prefix,
- *   the pass is a no-op); it is clamped so that the tile holding a sequence's
- *   newest token always stays in that sequence's own share. Needs the
- *   matrix-core decode kernel (Hq/Hkv in {2, 4, 8}) and block_size % 128 == 0
- *   (`block_size` is only read when shared_prefix_blocks != NULL). Whether the
- *   pass is launched is a property of the plan BUFFER (remembered like its
- *   geometry): re-plan the same buffer without the pointer to switch it off. */
+ * shared_prefix (optional, may be NULL; ABI v5): DEVICE pointer to int32[1 + batch]. [0] = the number of leading KV
+ *   blocks that the MEMBER sequences of the step have in common (identical block_tables[b][0 .. n) for every member
+ *   b), [1 + b] != 0 marks sequence b as a member — what the reference's prefix cache produces when requests start
+ *   with the same prompt prefix (engine/block_manager.py:58-82 hands a cache hit the block id of the earlier request;
+ *   requests prefilled before the first one was registered, :110-120, hold private copies and are not members).
+ *   A plan built with it makes the attention calls that consume it run a SHARED-PREFIX PASS: those blocks are read
+ *   once per pack of 16 / (Hq/Hkv) consecutive sequences instead of once per member, and the per-sequence kernel
+ *   starts a member behind them; results are merged like any split (same value up to the fp32 summation order).
+ *   The array is read on the device when the plan kernel AND the attention kernels run (graph replays see the current
+ *   values; it must stay valid as long as the plan is used, like context_lens). [0] = 0: no shared prefix, the pass
+ *   is a no-op. The count is clamped so that the tile holding a member's newest token always stays in that
+ *   sequence's own share. Needs the matrix-core decode kernel (Hq/Hkv in {2, 4, 8}) and block_size % 128 == 0
+ *   (`block_size` is only read when shared_prefix != NULL). Whether the pass is launched is a property of the plan
+ *   BUFFER (remembered like its geometry): re-plan the same buffer without the pointer to switch it off. */
 size_t nvl_decode_plan_bytes(void);
 int nvl_decode_plan(const int32_t* context_lens, int64_t batch,
                     int num_q_heads, int num_kv_heads, int64_t max_context,
-                    const int32_t* shared_prefix_blocks, int block_size,
+                    const int32_t* shared_prefix, int block_size,
                     void* plan, size_t plan_bytes, void* stream);
 
 /* Decode-step fusion of the three reference launches that precede the attention

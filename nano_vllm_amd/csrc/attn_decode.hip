@@ -60,9 +60,9 @@ __device__ __forceinline__ float dot8(const u32x4_t& a, const u32x4_t& b) {
 }
 
 // Inclusive prefix of ceil(len/chunk) into pre[1..B], pre[0] = 0. All 256 threads participate.
-// `skip`: leading tiles of every sequence that are NOT part of its share (the shared-prefix pass takes them).
+// `skip`: leading tiles that are NOT part of the share of a sequence with member[i] != 0 (the shared-prefix pass takes them).
 __device__ __forceinline__ void chunk_prefix(const int32_t* __restrict__ ctx, int batch, int chunk, int* pre,
-                                             int* wsum, int skip = 0) {
+                                             int* wsum, int skip = 0, const int32_t* __restrict__ member = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int carry = 0;
   if (threadIdx.x == 0) pre[0] = 0;
@@ -71,7 +71,8 @@ __device__ __forceinline__ void chunk_prefix(const int32_t* __restrict__ ctx, in
     int v = 0;
     if (i < batch) {
       const int len = ctx[i];
-      v = len > 0 ? max((len + chunk - 1) / chunk - skip, 0) : 0;
+      const int mine = (skip > 0 && member[i] != 0) ? skip : 0;
+      v = len > 0 ? max((len + chunk - 1) / chunk - mine, 0) : 0;
     }
     int s = v;
 #pragma unroll
@@ -106,12 +107,15 @@ constexpr int kMinTilesPerWave = 4;
 // the attention grid, where its share starts; the attention kernel reads ONE 16-byte record through the scalar cache
 // and goes. Later segments of a wave's share need no search at all: they always start at tile 0 of the next
 // (sequence, kv-head) pair, and the tile count of a sequence is ceil(context_len / 32).
-struct PlanHeader {          // 32 bytes, followed by nwaves PlanEntry records
-  int64_t total;             // tiles of the whole step = hkv * sum_b (ceil(len_b / 32) - sh_tiles)
+struct PlanHeader {          // 48 bytes, followed by nwaves PlanEntry records
+  int64_t total;             // tiles of the whole step = hkv * sum_b (ceil(len_b / 32) - [b is a member] sh_tiles)
   int64_t per;               // tiles per wave
   int32_t nwaves, batch, hkv;
-  int32_t sh_tiles;          // leading tiles of EVERY sequence that the shared-prefix pass computes (0: none)
+  int32_t sh_tiles;          // leading tiles of every MEMBER sequence that the shared-prefix pass computes (0: none)
+  const int32_t* member;     // [batch] != 0: the sequence starts with the shared blocks (the caller's array; sh_tiles > 0 only)
+  int64_t pad;
 };
+static_assert(sizeof(PlanHeader) % 16 == 0, "the wave records behind the header are 16-byte aligned");
 struct __attribute__((aligned(16))) PlanEntry { int32_t b, h, t0, nb; };   // first segment of a wave's share (b < 0: none)
 
 __global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restrict__ ctx, int batch, int hkv, int nwaves,
@@ -120,26 +124,29 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restr
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int* wsum = reinterpret_cast<int*>(smem_raw);
   int* pre = wsum + kWaves;
-  // Shared prefix: the caller says how many leading KV blocks every live sequence has in common. Whatever it says, the
-  // tile that takes a sequence's NEW token stays in that sequence's own share (the stream-K kernel stores the token and
-  // starts its softmax there): sh <= min over live sequences of floor((len - 1) / 32).
+  // Shared prefix: shared_blocks[0] = number of leading KV blocks the MEMBER sequences (shared_blocks[1 + b] != 0) have in
+  // common. Whatever it says, the tile that takes a member's NEW token stays in that sequence's own share (the stream-K
+  // kernel stores the token and starts its softmax there): sh <= min over live members of floor((len - 1) / 32).
   int sh = 0;
+  const int32_t* member = shared_blocks != nullptr ? shared_blocks + 1 : nullptr;
   if (shared_blocks != nullptr) {
-    __shared__ int smin;
-    if (threadIdx.x == 0) smin = 0x7fffffff;
+    int* smin = pre + batch + 1;                        // (one more int of the dynamic region: the launcher sizes it)
+    if (threadIdx.x == 0) *smin = 0x7fffffff;
     __syncthreads();
     int lmin = 0x7fffffff;
     for (int i = threadIdx.x; i < batch; i += 256) {
       const int len = ctx[i];
-      if (len > 0) lmin = min(lmin, (len - 1) / kTile);
+      if (len > 0 && member[i] != 0) lmin = min(lmin, (len - 1) / kTile);
     }
-    atomicMin(&smin, lmin);
+    atomicMin(smin, lmin);
     __syncthreads();
     const int want = shared_blocks[0];
-    sh = want > 0 ? min(want * tiles_per_block, smin) : 0;
-    if (smin == 0x7fffffff) sh = 0;                     // no live sequence
+    const int lowest = *smin;
+    sh = want > 0 ? min(want * tiles_per_block, lowest) : 0;
+    if (lowest == 0x7fffffff) sh = 0;                   // no live member
+    __syncthreads();
   }
-  chunk_prefix(ctx, batch, kTile, pre, wsum, sh);
+  chunk_prefix(ctx, batch, kTile, pre, wsum, sh, member);
   __syncthreads();
   const int64_t total = (int64_t)pre[batch] * hkv;
   int64_t per = (total + nwaves - 1) / nwaves;
@@ -151,6 +158,8 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restr
     hdr->batch = batch;
     hdr->hkv = hkv;
     hdr->sh_tiles = sh;
+    hdr->member = member;
+    hdr->pad = 0;
   }
   PlanEntry* ent = reinterpret_cast<PlanEntry*>(hdr + 1);
   for (int w = threadIdx.x; w < nwaves; w += 256) {
@@ -716,7 +725,8 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
 
   const int64_t wid = (int64_t)blockIdx.x * kWaves + wave;
   int64_t total, per;
-  int sh = 0;                // leading tiles of every sequence that belong to the shared-prefix pass (plan only)
+  int sh = 0;                // leading tiles of every MEMBER sequence that belong to the shared-prefix pass (plan only)
+  const int32_t* member = nullptr;
   PlanEntry first_seg = {-1, 0, 0, 0};
   if (plan != nullptr) {
     // per-step plan: header + this wave's record, two scalar loads (the addresses are wave-uniform); no LDS prefix,
@@ -728,6 +738,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     total = plan_ok ? plan->total : 0;
     per = plan->per;
     sh = plan->sh_tiles;
+    member = plan->member;
     if (plan_ok) first_seg = reinterpret_cast<const PlanEntry*>(plan + 1)[wid];
   } else {
     chunk_prefix(ctx, batch, kTile, pre, wsum);
@@ -760,6 +771,8 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     h_ = r / nb_;
     t0_ = r - h_ * nb_;
   };
+  // leading tiles of sequence bb that are not its own (0 without a shared prefix: no load)
+  auto sh_of = [&](int bb) { return (sh > 0 && __builtin_amdgcn_readfirstlane(member[bb]) != 0) ? sh : 0; };
   // the pair after (b_, h_): next kv-head of the same sequence, or head 0 of the next sequence that has tiles
   // (context_len 0 = graph padding). Only called when tiles remain (g + run < g1 <= total), so the scan terminates.
   auto advance = [&](int b_, int nb_, int h_, int& b2_, int& nb2_, int& h2_) {
@@ -770,7 +783,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     int bb = b_ + 1, n = 0;
     while (bb < batch) {
       const int len2 = __builtin_amdgcn_readfirstlane(ctx[bb]);
-      n = len2 > 0 ? (len2 + kTile - 1) / kTile - sh : 0;
+      n = len2 > 0 ? (len2 + kTile - 1) / kTile - sh_of(bb) : 0;
       if (n > 0) break;
       ++bb;
     }
@@ -785,10 +798,13 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   // nothing else happens between the loads.
   constexpr int kTL = KV8 ? kLoads8 : kLoads;
   u32x4_t kd[kTL], vd[kTL];
-  // (tile indices are relative to the sequence's OWN share: tile ti of the share is tile ti + sh of the sequence)
-  auto tile_block = [&](int bb, int ti) { return block_tables[(int64_t)bb * bt_stride + ((ti + sh) * kTile) / block_size]; };
-  auto tile_load = [&](int blk, int hh, int ti) {
-    const int t = (ti + sh) * kTile;
+  // (tile indices are relative to the sequence's OWN share: tile ti of the share is tile ti + shb of the sequence,
+  //  shb = sh_of(sequence))
+  auto tile_block = [&](int bb, int ti, int shb) {
+    return block_tables[(int64_t)bb * bt_stride + ((ti + shb) * kTile) / block_size];
+  };
+  auto tile_load = [&](int blk, int hh, int ti, int shb) {
+    const int t = (ti + shb) * kTile;
     if constexpr (KV8) {
       const int64_t base = (((int64_t)blk * hkv + hh) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
       const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
@@ -824,13 +840,15 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   }
   for (int64_t g = wid * per; g < g1;) {
     const int run = (int)min((int64_t)(nb - t0), g1 - g);
-    if (!prefetched) tile_load(tile_block(b, t0), h, t0);
+    const int shb = sh_of(b);
+    if (!prefetched) tile_load(tile_block(b, t0, shb), h, t0, shb);
     __builtin_amdgcn_sched_barrier(0);
     // the segment after this one (its first tile is requested under this segment's last tile); it starts at tile 0
     const bool has_next = g + run < g1;
     int b2 = 0, nb2 = 1, h2 = 0;
     constexpr int t02 = 0;
     if (has_next) advance(b, nb, h, b2, nb2, h2);
+    const int shb2 = has_next ? sh_of(b2) : 0;
     const int len = ctx[b];
     const bool owns_last = FUSED && (t0 + run == nb);
 
@@ -927,13 +945,14 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     const int len_cached = FUSED ? len - 1 : len;
 
     for (int ti = t0; ti < t0 + run; ++ti) {
-      const int t = (ti + sh) * kTile;
+      const int t = (ti + shb) * kTile;
       // which tile comes next (this segment's, or the first one of the next segment), and its block id: the table
       // lookup is issued HERE so that its round trip hides under the wait for the current tile
       const bool in_seg = ti + 1 < t0 + run;
       const bool has_pf = in_seg || has_next;
       const int pf_b = in_seg ? b : b2, pf_h = in_seg ? h : h2, pf_t = in_seg ? ti + 1 : t02;
-      const int pf_blk = has_pf ? tile_block(pf_b, pf_t) : 0;
+      const int pf_sh = in_seg ? shb : shb2;
+      const int pf_blk = has_pf ? tile_block(pf_b, pf_t, pf_sh) : 0;
       // registers -> this wave's LDS tile (K in swizzled 16-byte slots, V row-major padded), then the next tile's loads
       if constexpr (KV8) {
         // lane holds elements 16 (lane & 7) .. of row 8 i + (lane >> 3): bf16 16-byte chunks c0, c0 + 1 of that row
@@ -965,7 +984,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
           *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (has_pf) tile_load(pf_blk, pf_h, pf_t);
+      if (has_pf) tile_load(pf_blk, pf_h, pf_t, pf_sh);
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- S^T: two 16-token halves x four 32-dim chunks ------------------------------------------------
@@ -1044,15 +1063,16 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Shared-prefix pass (plans built with `shared_prefix_blocks`, nvl_decode_plan). When EVERY live sequence of a step
-// starts with the same `sh` tiles of KV (prefix-cache hits on one system prompt — BASELINE config 3: 256 sequences x a
-// 512-token prompt prefix), those tiles are read once per PACK of 16 / G sequences instead of once per sequence: the 16
+// Shared-prefix pass (plans built with `shared_prefix`, nvl_decode_plan). When the MEMBER sequences of a step start
+// with the same `sh` tiles of KV (prefix-cache hits on one system prompt — BASELINE config 3: 256 sequences x a
+// 512-token prompt prefix, of which the ones prefilled after the first batch share one copy), those tiles are read once
+// per PACK of 16 / G consecutive sequences instead of once per sequence (non-members of a pack ride along as zero columns): the 16
 // MFMA columns that carry one sequence's G heads (plus zero padding) in decode_mfma8_kernel carry the heads of 16 / G
 // sequences here — same K / V fragments, same online softmax, every column useful. One workgroup per (pack, kv head);
 // its four waves take a quarter of the prefix tiles each (tile loads one tile ahead, through L2 on purpose: the other
 // packs read the same tiles) and merge lane by lane through LDS. The result is ONE more split partial per (sequence,
 // head) — (m, l, O) in the log2 domain like every other — in the slot the stream-K kernel never writes (slots - 1);
-// decode_stream_combine_kernel folds it in. The stream-K kernel itself starts every sequence at tile `sh` (PlanHeader).
+// decode_stream_combine_kernel folds it in. The stream-K kernel itself starts every member at tile `sh` (PlanHeader).
 // The new token's q is needed here as well: FUSED recomputes norm + rotation from the raw qkv row (bit-identical to the
 // stream-K kernel's, same helpers); K / V of the new token are the stream-K kernel's business alone.
 template <bool FUSED, bool KV8, int G, bool SLABS>
@@ -1066,58 +1086,27 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int sh = plan->sh_tiles;
   if (sh <= 0 || plan->batch != batch || plan->hkv != hkv) return;          // (workgroup-uniform)
+  const int32_t* __restrict__ member = plan->member;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane & 15, rq = lane >> 4;      // prologue view: 16 lanes x 8 dims = one row
   const int col = lane & 15, quad = lane >> 4;    // MFMA view: one (sequence, head) column per lane
   const int hq = hkv * G;
   const int pack = blockIdx.x / hkv, h = blockIdx.x - pack * hkv;
   const int b0 = pack * P;
-  // the block-table row the prefix tiles are looked up in: the pack's first live sequence (all live rows agree on them)
+  // the block-table row the prefix tiles are looked up in: the pack's first live member (all members agree on them)
   int tb = -1;
 #pragma unroll
   for (int j = P - 1; j >= 0; --j) {
     const int bj = b0 + j;
-    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0) tb = bj;
+    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0 && __builtin_amdgcn_readfirstlane(member[bj]) != 0) tb = bj;
   }
-  if (tb < 0) return;                                                       // a pack of graph padding
+  if (tb < 0) return;                                                       // a pack of graph padding / of non-members
   unsigned char* k_lds = smem_raw + wave * kMWaveLds;
   unsigned char* v_lds = k_lds + kTile * kMKRow;
   int kfrag[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) kfrag[c] = col * kMKRow + (((4 * c + quad) ^ col) << 4);
   const int vfrag = (4 * quad + (col >> 2)) * kMVRow + (col & 3) * 8;
-
-  // ---- q tile [16 columns][128]: column r = (sequence b0 + r / G, head h G + r % G); rows of dead sequences are zero ----
-  {
-    u32x4_t wq = {0u, 0u, 0u, 0u};
-    if constexpr (FUSED) {
-      if (fa.q_norm_w != nullptr) wq = *reinterpret_cast<const u32x4_t*>(fa.q_norm_w + sub * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = rq + 4 * it;
-      const int seq = b0 + r / G, hd = r % G;
-      const int seq_c = seq < batch ? seq : batch - 1;
-      const int len = ctx[seq_c];
-      const bool live = seq < batch && len > 0;
-      u32x4_t qh;
-      if constexpr (FUSED) {
-        int64_t pos = len > 0 ? len - 1 : 0;
-        pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
-        const RopeRegs rr = load_rope_regs(fa.cos_sin + pos * 128, sub);
-        qh = load_qkv8<SLABS>(q, (int64_t)seq_c * fa.qkv_tok_stride + (h * G + hd) * 128 + sub * 8, fa);
-        qh = norm_rope_head_regs(qh, fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
-      } else {
-        qh = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)seq_c * hq + h * G + hd) * 128 + sub * 8);
-      }
-      if (!live) qh = u32x4_t{0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4_t*>(k_lds + r * 256 + sub * 16) = qh;
-    }
-  }
-  bf16x8_t qb[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    qb[c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(k_lds + col * 256 + (4 * c + quad) * 16));
 
   constexpr int kTL = KV8 ? kLoads8 : kLoads;
   u32x4_t kd[kTL], vd[kTL];
@@ -1143,13 +1132,48 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
     }
   };
 
-  const int t_begin = (wave * sh) / kWaves, t_end = ((wave + 1) * sh) / kWaves;   // this wave's quarter of the prefix
+  // this wave's quarter of the prefix; its first tile is requested BEFORE the q prologue (the two are independent: the
+  // prologue's own loads — context length, rotation table row, qkv row — are a chain of L2 round trips of their own)
+  const int t_begin = (wave * sh) / kWaves, t_end = ((wave + 1) * sh) / kWaves;
+  if (t_begin < t_end) tile_load(tile_block(t_begin), t_begin);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // ---- q tile [16 columns][128]: column r = (sequence b0 + r / G, head h G + r % G); rows of dead sequences are zero ----
+  {
+    u32x4_t wq = {0u, 0u, 0u, 0u};
+    if constexpr (FUSED) {
+      if (fa.q_norm_w != nullptr) wq = *reinterpret_cast<const u32x4_t*>(fa.q_norm_w + sub * 8);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = rq + 4 * it;
+      const int seq = b0 + r / G, hd = r % G;
+      const int seq_c = seq < batch ? seq : batch - 1;
+      const int len = ctx[seq_c];
+      const bool live = seq < batch && len > 0 && member[seq_c] != 0;
+      u32x4_t qh;
+      if constexpr (FUSED) {
+        int64_t pos = len > 0 ? len - 1 : 0;
+        pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
+        const RopeRegs rr = load_rope_regs(fa.cos_sin + pos * 128, sub);
+        qh = load_qkv8<SLABS>(q, (int64_t)seq_c * fa.qkv_tok_stride + (h * G + hd) * 128 + sub * 8, fa);
+        qh = norm_rope_head_regs(qh, fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
+      } else {
+        qh = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)seq_c * hq + h * G + hd) * 128 + sub * 8);
+      }
+      if (!live) qh = u32x4_t{0u, 0u, 0u, 0u};
+      *reinterpret_cast<u32x4_t*>(k_lds + r * 256 + sub * 16) = qh;
+    }
+  }
+  bf16x8_t qb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    qb[c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(k_lds + col * 256 + (4 * c + quad) * 16));
+
   float m_run = kNegBig, l_run = 0.f;
   f32x4_t oacc[8];
 #pragma unroll
   for (int db = 0; db < 8; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  if (t_begin < t_end) tile_load(tile_block(t_begin), t_begin);
-  __builtin_amdgcn_sched_barrier(0);
   for (int ti = t_begin; ti < t_end; ++ti) {
     const bool has_pf = ti + 1 < t_end;
     const int pf_blk = has_pf ? tile_block(ti + 1) : 0;
@@ -1261,7 +1285,7 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
       for (int r = 0; r < 4; ++r) oacc[db][r] = oacc[db][r] * fa_ + other[(db * 4 + r) * 64 + lane] * fb_;
   }
   const int seq = b0 + col / G, hd = col % G;
-  if (seq < batch && ctx[seq] > 0) {
+  if (seq < batch && ctx[seq] > 0 && member[seq] != 0) {
     const int64_t pidx = ((int64_t)seq * hq + h * G + hd) * slots + (slots - 1);
     float* dst = part_o + pidx * 128 + 4 * quad;
 #pragma unroll
@@ -1299,7 +1323,7 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
   // step has one is in the plan header) — requested with everything else, folded in last
   const int ps = prefix_slot >= 0 ? prefix_slot : 0;
   const float m_p = ml[ps * 2], l_p = ml[ps * 2 + 1], o_p = po[ps * 128 + d];
-  const bool has_pre = prefix_slot >= 0 && plan->sh_tiles > 0;
+  const bool has_pre = prefix_slot >= 0 && plan->sh_tiles > 0 && plan->member[b] != 0;
   float m_s[kSpec], l_s[kSpec], o_s[kSpec];
 #pragma unroll
   for (int c = 0; c < kSpec; ++c) {
@@ -1760,13 +1784,14 @@ extern "C" size_t nvl_decode_plan_bytes(void) {
 }
 
 extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int num_q_heads, int num_kv_heads,
-                               int64_t max_context, const int32_t* shared_prefix_blocks, int block_size, void* plan,
+                               int64_t max_context, const int32_t* shared_prefix, int block_size, void* plan,
                                size_t plan_bytes, void* stream) {
+  const int32_t* shared_prefix_blocks = shared_prefix;       // [0] = blocks, [1 + b] = member flags (include/nvl.h)
   const char* who = "nvl_decode_plan";
   NVL_REQUIRE(context_lens && plan, "%s: null pointer", who);
   if (shared_prefix_blocks != nullptr) {
     const int G = num_kv_heads > 0 ? num_q_heads / num_kv_heads : 0;
-    NVL_REQUIRE((uintptr_t)shared_prefix_blocks % 4 == 0, "%s: shared_prefix_blocks must be 4-byte aligned", who);
+    NVL_REQUIRE((uintptr_t)shared_prefix_blocks % 4 == 0, "%s: shared_prefix must be 4-byte aligned", who);
     NVL_REQUIRE(block_size > 0 && block_size % 128 == 0, "%s: a shared prefix needs block_size %% 128 == 0 (got %d)", who, block_size);
     NVL_REQUIRE((G == 8 && !use_valu_g8()) || ((G == 2 || G == 4) && use_mfma_small_g()),
                 "%s: a shared prefix needs the matrix-core decode kernel (Hq/Hkv in {2, 4, 8}; got %d)", who, G);
@@ -1778,7 +1803,7 @@ extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int n
   NVL_REQUIRE(plan_bytes >= nvl_decode_plan_bytes(), "%s: plan buffer %zu B < required %zu B", who, plan_bytes, nvl_decode_plan_bytes());
   if (batch == 0) return NVL_OK;
   const int nwaves = (int)mfma8_grid(batch, num_kv_heads, max_context, true) * kWaves;
-  const size_t lds = kWaves * sizeof(int) + (size_t)(batch + 1) * sizeof(int);
+  const size_t lds = kWaves * sizeof(int) + (size_t)(batch + 2) * sizeof(int);      // wave sums, tile prefix, shortest row
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set) {

@@ -153,20 +153,32 @@ def _align(n: int, a: int = 16) -> int:
     return (n + a - 1) // a * a
 
 
-def shared_prefix_blocks(bt: np.ndarray, lens: np.ndarray, block_size: int) -> int:
-    """Number of leading KV blocks that EVERY row of a decode batch has in common: identical block ids in
-    bt[:, 0 .. k) — what the prefix cache hands out when all requests start with the same tokens
-    (block_manager.py:58-82: a cache hit appends the SAME block id to each sequence's table). Only blocks that lie
-    completely before the newest token of the shortest row count (k <= (min(lens) - 1) // block_size): the block a
-    sequence is still writing is never shared."""
+def shared_prefix_group(bt: np.ndarray, lens: np.ndarray, block_size: int):
+    """(k, member): the rows of a decode batch that start with the same KV blocks, and how many. The group is the set of
+    rows whose FIRST block id is the most frequent one; k = the number of leading columns of bt on which all of them
+    agree — what the prefix cache hands out when requests start with the same tokens (block_manager.py:58-82: a cache
+    hit appends the block id of the request that registered it; requests prefilled in the step that first computed the
+    prefix hold private copies, :110-120, and are not members). Only blocks that lie completely before the newest token
+    of the shortest member count (k <= (min(len) - 1) // block_size): the block a member is still writing is never
+    shared. (0, None): nothing to share."""
     n = len(lens)
     if n < 2:
-        return 0
-    cap = min(int((int(lens.min()) - 1) // block_size), bt.shape[1])
-    if cap <= 0 or bt[0, 0] < 0 or not (bt[1:n, 0] == bt[0, 0]).all():       # (the common case: nothing shared)
-        return 0
-    same = (bt[1:n, :cap] == bt[0, :cap]).all(axis=0)
-    return cap if same.all() else int(np.argmin(same))
+        return 0, None
+    first = bt[:n, 0]
+    vals, counts = np.unique(first, return_counts=True)
+    if len(vals) == n:                                          # (the common case: all different)
+        return 0, None
+    j = int(counts.argmax())
+    if counts[j] < 2 or vals[j] < 0:
+        return 0, None
+    member = first == vals[j]
+    rows = np.nonzero(member)[0]
+    cap = min(int((int(lens[rows].min()) - 1) // block_size), bt.shape[1])
+    if cap <= 0:
+        return 0, None
+    same = (bt[rows, :cap] == bt[rows[0], :cap]).all(axis=0)
+    k = cap if same.all() else int(np.argmin(same))
+    return (k, member) if k > 0 else (0, None)
 
 
 class _Stage:
@@ -405,7 +417,7 @@ class ModelRunner:
         self.dstage = _Stage([
             ("ids", np.int64, (mb,)), ("pos", np.int64, (mb,)), ("rng", np.uint64, (2,)), ("rkey", np.int64, (mb,)),
             ("slots", np.int32, (mb,)), ("ctx", np.int32, (mb,)), ("temps", np.float32, (mb,)),
-            ("src", np.int32, (mb,)), ("shp", np.int32, (4,)), ("bt", np.int32, (mb, w)),
+            ("src", np.int32, (mb,)), ("shp", np.int32, (1 + mb,)), ("bt", np.int32, (mb, w)),
         ], self.device, host_copies=2)
         for image in self.dstage.nps:
             image["slots"][:] = -1
@@ -586,7 +598,11 @@ class ModelRunner:
             bt[i, :len(t)] = t
             bt[i, len(t):] = -1
         key[:n, 0], key[:n, 1], key[:n, 2] = ids, nblk, gen
-        st["shp"][0] = self._prefix_blocks_worth_a_pass(bt, lens, n) if self.share_prefix else 0
+        # shared-prefix pass: [0] = leading blocks the member rows have in common (0: plain step), [1 + row] = member
+        k, member = self._prefix_group_worth_a_pass(bt, lens, n) if self.share_prefix else (0, None)
+        st["shp"][0] = k
+        if k > 0:
+            st["shp"][1:1 + n] = member
         # neutralise rows used by a previous, larger batch (graph padding: slot -1, context 0)
         dirty = self._dirty[self.dstage.cur]
         if dirty > n:
@@ -596,16 +612,17 @@ class ModelRunner:
         self._dirty[self.dstage.cur] = n
         return n
 
-    def _prefix_blocks_worth_a_pass(self, bt: np.ndarray, lens: np.ndarray, n: int) -> int:
-        """Shared leading blocks of the batch, or 0 when the K/V bytes the shared-prefix pass would save per layer
-        (the blocks are read once per pack of 16 / G sequences instead of once per sequence) do not pay for its launch."""
-        k = shared_prefix_blocks(bt[:n], lens, self.block_size)
+    def _prefix_group_worth_a_pass(self, bt: np.ndarray, lens: np.ndarray, n: int):
+        """shared_prefix_group of the batch, or (0, None) when the K/V bytes the shared-prefix pass would save per layer
+        (the blocks are read once per pack of 16 / G sequences instead of once per member) do not pay for its launch."""
+        k, member = shared_prefix_group(bt[:n], lens, self.block_size)
         if k == 0:
-            return 0
+            return 0, None
         pack = 16 // (self.geo["heads"] // self.geo["kv_heads"])
         esize = 1 if self.config.kv_cache_dtype == "fp8" else 2
-        saved = k * self.block_size * (n - -(-n // pack)) * self.geo["kv_heads"] * 2 * 128 * esize
-        return k if saved >= self.share_prefix_min_bytes else 0
+        m = int(member.sum())
+        saved = k * self.block_size * (m - -(-m // pack)) * self.geo["kv_heads"] * 2 * 128 * esize
+        return (k, member) if saved >= self.share_prefix_min_bytes else (0, None)
 
     # ------------------------------------------------------------------ forward
     def _next_rng(self, st: _Stage) -> None:
@@ -627,11 +644,12 @@ class ModelRunner:
 
     def _decode_rows(self, r0: int, r1: int, ws, sampler, plan=None, prefix: bool = False):
         """Decode forward for rows [r0, r1) of the static device buffers, on the current stream. `prefix`: the plan
-        carries the step's shared-prefix block count (staged as `shp`), the attention launches run the shared pass."""
+        carries the step's shared-prefix group (staged as `shp`), the attention launches run the shared pass."""
         t = self.dstage.t
+        assert not prefix or r0 == 0           # (the member flags are staged per row of the whole batch)
         if plan is not None:
             ops.decode_plan(t["ctx"][r0:r1], self.geo["heads"], self.geo["kv_heads"], self.config.max_model_len, plan,
-                            shared_prefix_blocks=t["shp"][:1] if prefix else None, block_size=self.block_size)
+                            shared_prefix=t["shp"] if prefix else None, block_size=self.block_size)
         set_context(False, slot_mapping=t["slots"][r0:r1], context_lens=t["ctx"][r0:r1],
                     block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len,
                     decode_plan=plan)

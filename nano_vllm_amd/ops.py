@@ -337,20 +337,22 @@ def decode_plan_bytes() -> int:
 
 
 def decode_plan(context_lens: torch.Tensor, num_q_heads: int, num_kv_heads: int, max_context: int,
-                plan: torch.Tensor | None = None, shared_prefix_blocks: torch.Tensor | None = None,
+                plan: torch.Tensor | None = None, shared_prefix: torch.Tensor | None = None,
                 block_size: int = 256) -> torch.Tensor:
     """Per-step work plan of the decode attention launches (same for every layer of the step): `plan` is a uint8
-    device buffer of decode_plan_bytes() bytes, allocated when None. `shared_prefix_blocks`: int32 device tensor whose
-    first element is the number of leading KV blocks every live sequence has in common — the attention calls that
-    consume this plan then run the shared-prefix pass (include/nvl.h)."""
+    device buffer of decode_plan_bytes() bytes, allocated when None. `shared_prefix`: int32 device tensor [1 + batch] —
+    [0] = number of leading KV blocks the member sequences have in common, [1 + b] != 0 marks sequence b as a member;
+    the attention calls that consume this plan then run the shared-prefix pass, and read the member flags from this
+    tensor's memory when they run (include/nvl.h)."""
     _dev(context_lens, "context_lens")
     assert context_lens.dtype == torch.int32 and context_lens.is_contiguous()
     if plan is None:
         plan = torch.empty(decode_plan_bytes(), dtype=torch.uint8, device=context_lens.device)
     shp = None
-    if shared_prefix_blocks is not None:
-        assert shared_prefix_blocks.dtype == torch.int32 and shared_prefix_blocks.device == context_lens.device
-        shp = shared_prefix_blocks.data_ptr()
+    if shared_prefix is not None:
+        assert shared_prefix.dtype == torch.int32 and shared_prefix.device == context_lens.device
+        assert shared_prefix.is_contiguous() and shared_prefix.numel() >= 1 + context_lens.numel()
+        shp = shared_prefix.data_ptr()
     _check(lib().nvl_decode_plan(context_lens.data_ptr(), context_lens.numel(), num_q_heads, num_kv_heads, max_context,
                                  shp, block_size, plan.data_ptr(), plan.numel(), _stream()))
     return plan

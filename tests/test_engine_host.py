@@ -87,13 +87,21 @@ class FakeRunner(ModelRunner):
             assert (row[len(s.block_table):] == -1).all()
             self.checked_rows += 1
         assert (st["ctx"][n:self.max_bs] == 0).all() and (st["slots"][n:self.max_bs] == -1).all()
-        # shared-prefix block count of the step (0 unless the pass is switched on): against a direct count on the sequences
-        want = 0
+        # shared-prefix group of the step (count 0 unless the pass is switched on): against a direct count on the sequences
+        want, members = 0, []
         if self.share_prefix and n >= 2:
-            cap = (min(s.num_tokens for s in seqs) - 1) // bs
-            while want < cap and all(s.block_table[want] == seqs[0].block_table[want] for s in seqs):
-                want += 1
+            firsts = [s.block_table[0] for s in seqs]
+            top = max(set(firsts), key=lambda v: (firsts.count(v), -v))
+            members = [i for i, v in enumerate(firsts) if v == top]
+            if len(members) >= 2:
+                cap = (min(seqs[i].num_tokens for i in members) - 1) // bs
+                ref0 = seqs[members[0]].block_table
+                while want < cap and all(seqs[i].block_table[want] == ref0[want] for i in members):
+                    want += 1
         assert st["shp"][0] == want, (int(st["shp"][0]), want)
+        if want:
+            assert list(np.nonzero(st["shp"][1:1 + n])[0]) == members
+            self.shared_partial = getattr(self, "shared_partial", 0) + (len(members) < n)
         self.shared_seen = max(getattr(self, "shared_seen", 0), want)
         toks = _next_token(ids, st["pos"][:n], st["rkey"][:n])
         self.tokens[:n] = toks
@@ -176,11 +184,13 @@ def test_lookahead_equals_serial_with_more_prompts_than_rows(seed):
 
 
 @pytest.mark.parametrize("seed", [0, 1])
-def test_staged_shared_prefix_block_count(seed):
-    """Requests that start with the same tokens get the same leading block ids from the prefix cache
-    (block_manager.py:58-82); every staged decode image carries how many leading blocks ALL its rows share (checked in
-    FakeRunner._launch_decode against a direct count) — 0 while a request without the prefix is in the batch, and never
-    the block a row is still writing. The same workload generates the same tokens with the count switched off."""
+def test_staged_shared_prefix_group(seed):
+    """Requests that start with the same tokens get the same leading block ids from the prefix cache once the first of
+    them has been registered (block_manager.py:58-82, :110-120: the requests of the prefill step that first computes the
+    prefix keep private copies). Every staged decode image carries the group of rows that share their leading blocks and
+    how many blocks that is (checked in FakeRunner._launch_decode against a direct count) — never the block a member is
+    still writing; rows outside the group (other prompts, private copies) are not members. The same workload generates
+    the same tokens with the staging switched off."""
     r = Random(seed)
     bs = 256
     common = [r.randint(0, VOCAB - 1) for _ in range(2 * bs + 17)]
@@ -188,7 +198,9 @@ def test_staged_shared_prefix_block_count(seed):
     prompts.insert(2, [r.randint(0, VOCAB - 1) for _ in range(40)])
     prompts.append(common[:2 * bs])              # ends exactly on the shared blocks' edge: its newest token opens block 2
     sps = [SamplingParams(temperature=0.0, ignore_eos=True, max_tokens=m) for m in (9, 30, 4, 12, 25, 300, 7, 18, 11)]
-    kw = dict(max_num_seqs=8, max_model_len=2048, num_kvcache_blocks=40, max_num_batched_tokens=1024)
+    # a 1200-token budget: the first prefill step takes the first request and part of the second (both compute the prefix:
+    # private copies), the later ones hit the cache
+    kw = dict(max_num_seqs=8, max_model_len=2048, num_kvcache_blocks=40, max_num_batched_tokens=1200)
     outs = []
     for on in (True, False):
         eng = _engine(True, **kw)
@@ -196,33 +208,37 @@ def test_staged_shared_prefix_block_count(seed):
         eng.model_runner.share_prefix_min_bytes = 0.0
         outs.append(_generate(eng, prompts, sps))
         assert eng.model_runner.shared_seen == (2 if on else 0)
+        assert not on or eng.model_runner.shared_partial > 0         # steps in which some rows were not members
     assert outs[0] == outs[1]
 
 
-def test_shared_prefix_blocks_helper_and_the_launch_threshold():
-    from nano_vllm_amd.engine.runner import shared_prefix_blocks
-    bt = np.full((5, 8), -1, dtype=np.int32)
-    bt[:, :3] = [7, 9, 4]
-    bt[:, 3] = [10, 11, 12, 13, 14]
-    lens = np.array([900, 800, 1000, 770, 1024])
-    assert shared_prefix_blocks(bt, lens, 256) == 3
-    assert shared_prefix_blocks(bt, np.array([900, 800, 1000, 769, 1024]), 256) == 3      # (769 - 1) // 256 = 3
-    assert shared_prefix_blocks(bt, np.array([900, 800, 1000, 768, 1024]), 256) == 2      # block 2 holds that row's newest token
-    assert shared_prefix_blocks(bt[:1], lens[:1], 256) == 0                                  # one row shares with nobody
+def test_shared_prefix_group_helper_and_the_launch_threshold():
+    from nano_vllm_amd.engine.runner import shared_prefix_group
+    bt = np.full((6, 8), -1, dtype=np.int32)
+    bt[:5, :3] = [7, 9, 4]
+    bt[:5, 3] = [10, 11, 12, 13, 14]
+    bt[5, :4] = [20, 21, 22, 23]                 # a private copy of the same content: not a member
+    lens = np.array([900, 800, 1000, 770, 1024, 1000])
+    k, mem = shared_prefix_group(bt, lens, 256)
+    assert k == 3 and mem.tolist() == [True] * 5 + [False]
+    assert shared_prefix_group(bt, np.array([900, 800, 1000, 769, 1024, 1000]), 256)[0] == 3      # (769 - 1) // 256 = 3
+    assert shared_prefix_group(bt, np.array([900, 800, 1000, 768, 1024, 1000]), 256)[0] == 2      # block 2 holds that row's newest token
+    assert shared_prefix_group(bt, np.array([900, 800, 1000, 770, 1024, 10]), 256)[0] == 3        # a short NON-member does not clamp
+    assert shared_prefix_group(bt[:1], lens[:1], 256) == (0, None)                                   # one row shares with nobody
     bt2 = bt.copy()
     bt2[3, 1] = 99
-    assert shared_prefix_blocks(bt2, lens, 256) == 1
-    bt2[4, 0] = 98
-    assert shared_prefix_blocks(bt2, lens, 256) == 0
-    assert shared_prefix_blocks(np.full((4, 8), -1, dtype=np.int32), np.array([300] * 4), 256) == 0   # empty tables
-    # the threshold: K/V bytes saved per layer = blocks x 256 tokens x (rows - packs) x Hkv x 2 x 128 x 2 B
+    assert shared_prefix_group(bt2, lens, 256)[0] == 1                  # members agree on the first block only
+    bt2[:, 0] = np.arange(6)
+    assert shared_prefix_group(bt2, lens, 256) == (0, None)             # all first blocks differ
+    assert shared_prefix_group(np.full((4, 8), -1, dtype=np.int32), np.array([300] * 4), 256) == (0, None)   # empty tables
+    # the threshold: K/V bytes saved per layer = blocks x 256 tokens x (members - packs) x Hkv x 2 x 128 x 2 B
     eng = _engine(True, max_num_seqs=8, max_model_len=2048, num_kvcache_blocks=40)
     run = eng.model_runner                       # geometry: 4 query heads, 2 kv heads => packs of 8 rows
     saved = 3 * 256 * (5 - 1) * 2 * 2 * 128 * 2
     run.share_prefix_min_bytes = saved
-    assert run._prefix_blocks_worth_a_pass(bt, lens, 5) == 3
+    assert run._prefix_group_worth_a_pass(bt, lens, 6)[0] == 3
     run.share_prefix_min_bytes = saved + 1
-    assert run._prefix_blocks_worth_a_pass(bt, lens, 5) == 0
+    assert run._prefix_group_worth_a_pass(bt, lens, 6) == (0, None)
 
 
 @pytest.mark.parametrize("seed", range(6))

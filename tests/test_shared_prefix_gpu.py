@@ -1,4 +1,4 @@
-"""Shared-prefix pass of the decode attention (nvl_decode_plan's `shared_prefix_blocks`, ABI v5) against the plain
+"""Shared-prefix pass of the decode attention (nvl_decode_plan's `shared_prefix`, ABI v5) against the plain
 launch and against the CPU oracle.
 
 The reference's prefix cache (engine/block_manager.py:58-82) gives every request that starts with the same tokens the
@@ -29,18 +29,25 @@ def g(seed):
     return torch.Generator().manual_seed(seed)
 
 
-def _tables(lens, shared, gen):
-    """Block tables whose first `shared` columns hold the same block ids in every LIVE row (what the prefix cache hands
-    out), the rest private and shuffled; -1 padded to the engine's width (model_runner.py:125)."""
+def _tables(lens, shared, gen, private=()):
+    """Block tables whose first `shared` columns hold the same block ids in every row that is not in `private` (what the
+    prefix cache hands out; `private` rows hold their own copies, like the requests prefilled before the prefix was
+    registered), the rest private and shuffled; -1 padded to the engine's width (model_runner.py:125)."""
     nb = [(n + BS - 1) // BS for n in lens]
-    total = shared + sum(max(n - shared, 0) for n in nb) + 3
+    total = shared + sum(n if i in private else max(n - shared, 0) for i, n in enumerate(nb)) + 3
     perm = torch.randperm(total, generator=gen).tolist()
     common, rest = perm[:shared], iter(perm[shared:])
     bt = torch.full((len(lens), MAX_CTX // BS), -1, dtype=torch.int32)
     for i, n in enumerate(nb):
         for j in range(n):
-            bt[i, j] = common[j] if j < shared else next(rest)
+            bt[i, j] = common[j] if (j < shared and i not in private) else next(rest)
     return bt, total
+
+
+def _shp(k, lens, private=()):
+    """The plan's shared-prefix argument: [k, member flag per row]. Padding rows (context 0) carry a stale flag of 1 on
+    purpose — the engine does not clear flags of rows a smaller batch no longer uses."""
+    return torch.tensor([k] + [0 if i in private else 1 for i in range(len(lens))], dtype=torch.int32, device="cuda")
 
 
 def _rope_table():
@@ -50,8 +57,11 @@ def _rope_table():
 
 
 # rows: live lengths all beyond the shared blocks, padding rows (context 0) inside and at the end of packs, a row whose
-# newest token is the first one behind the shared blocks, 19 rows = not a multiple of any pack size (2, 4, 8)
-LENS = [513, 700, 0, 1024, 1025, 2048, 515, 0, 0, 640, 4096, 513, 900, 901, 0, 777, 1300, 520, 3000]
+# newest token is the first one behind the shared blocks, 19 rows = not a multiple of any pack size (2, 4, 8); rows 1, 12
+# and 13 are NOT members (private copies of their leading blocks; row 1 is even too short to hold two shared blocks):
+# a pack with one non-member (rows 0-1 at G = 8), and a pack of non-members only (rows 12-13 at G = 8)
+LENS = [513, 300, 0, 1024, 1025, 2048, 515, 0, 0, 640, 4096, 513, 900, 901, 0, 777, 1300, 520, 3000]
+PRIVATE = (1, 12, 13)
 
 
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (16, 2), (64, 8)])
@@ -60,11 +70,11 @@ LENS = [513, 700, 0, 1024, 1025, 2048, 515, 0, 0, 640, 4096, 513, 900, 901, 0, 7
 def test_fused_decode_with_a_shared_prefix_pass(ops, hq, hkv, shared, kv):
     """nvl_paged_attn_decode_fused driven by a plan that carries `shared` common blocks vs the same launch with a
     plain plan: K/V caches bit for bit, outputs to 1e-2 * absmax (order of the fp32 merge), and output + LSE against
-    the oracle on the cache the kernels left behind; padded rows stay zero. shared_prefix_blocks = 0 through the same
+    the oracle on the cache the kernels left behind; padded rows stay zero. A count of 0 through the same
     pointer: the pass finds nothing to do and the launch is the plain one bit for bit."""
     gen = g(300 + shared)
     b = len(LENS)
-    bt, total = _tables(LENS, shared, gen)
+    bt, total = _tables(LENS, shared, gen, PRIVATE)
     dt = torch.float8_e4m3fn if kv == "fp8" else BF16
     kc = (torch.randn(total, hkv, BS, 128, generator=gen) * 0.7).to(dt)
     vc = (torch.randn(total, hkv, BS, 128, generator=gen) * 0.7).to(dt)
@@ -87,8 +97,8 @@ def test_fused_decode_with_a_shared_prefix_pass(ops, hq, hkv, shared, kv):
         return o, lse, k1, v1
 
     o0, lse0, k0, v0 = run(ops.decode_plan(dctx, hq, hkv, MAX_CTX))
-    shp = torch.tensor([shared, 0, 0, 0], dtype=torch.int32, device="cuda")
-    plan_px = ops.decode_plan(dctx, hq, hkv, MAX_CTX, shared_prefix_blocks=shp, block_size=BS)
+    shp = _shp(shared, LENS, PRIVATE)
+    plan_px = ops.decode_plan(dctx, hq, hkv, MAX_CTX, shared_prefix=shp, block_size=BS)
     o1, lse1, k1, v1 = run(plan_px)
     assert torch.equal(k1.view(torch.uint8), k0.view(torch.uint8)) and torch.equal(v1.view(torch.uint8), v0.view(torch.uint8))
     live = [i for i, n in enumerate(LENS) if n > 0]
@@ -109,22 +119,23 @@ def test_fused_decode_with_a_shared_prefix_pass(ops, hq, hkv, shared, kv):
         assert float((o1.cpu().float()[live] - o_ref.float()[live]).abs().max()) <= 2e-2 * float(o_ref.float()[live].abs().max())
         assert float((lse1.cpu()[live] - lse_ref[live]).abs().max()) <= 2e-3
     # the same plan buffer, re-planned with a count of zero: nothing shared this step
-    shp.zero_()
-    ops.decode_plan(dctx, hq, hkv, MAX_CTX, plan=plan_px, shared_prefix_blocks=shp, block_size=BS)
+    shp[0] = 0
+    ops.decode_plan(dctx, hq, hkv, MAX_CTX, plan=plan_px, shared_prefix=shp, block_size=BS)
     o2, lse2, k2, v2 = run(plan_px)
     assert torch.equal(o2, o0) and torch.equal(lse2, lse0) and torch.equal(k2.view(torch.uint8), k0.view(torch.uint8))
 
 
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1)])
 def test_unfused_decode_clamps_the_shared_prefix_to_the_shortest_row(ops, hq, hkv):
-    """nvl_paged_attn_decode (K/V already stored) with two common blocks claimed while one row ends INSIDE the second
-    one (500 tokens: its tail is the common block's content) and one row is a single token: the device clamps the pass
-    to floor((min len - 1) / 32) tiles — 0 with the one-token row in the batch (bit-identical to the plain launch), 15
-    tiles = 480 tokens without it — and every row still matches the oracle."""
+    """nvl_paged_attn_decode (K/V already stored) with two common blocks claimed while one member ends INSIDE the second
+    one (500 tokens: its tail is the common block's content) and one is a single token: the device clamps the pass to
+    floor((min member len - 1) / 32) tiles — 0 with the one-token member in the batch (bit-identical to the plain
+    launch), 15 tiles = 480 tokens without it or when that row is not a member — and every row still matches the oracle."""
     gen = g(311)
-    for lens in ([600, 500, 1, 2048, 513], [600, 500, 0, 2048, 513, 512, 900]):
+    for lens, private in (([600, 500, 1, 2048, 513], ()), ([600, 500, 0, 2048, 513, 512, 900], ()),
+                          ([600, 500, 1, 2048, 513], (2,))):
         b = len(lens)
-        bt, total = _tables(lens, 2, gen)
+        bt, total = _tables(lens, 2, gen, private)
         kc = torch.randn(total, BS, hkv, 128, generator=gen).to(BF16)       # token-major (the oracle's layout)
         vc = torch.randn(total, BS, hkv, 128, generator=gen).to(BF16)
         q = torch.randn(b, hq, 128, generator=gen).to(BF16)
@@ -138,13 +149,13 @@ def test_unfused_decode_clamps_the_shared_prefix_to_the_shortest_row(ops, hq, hk
         lse0 = torch.zeros(b, hq, dtype=torch.float32, device="cuda")
         o0 = ops.paged_attn_decode(dq, dk, dv, dbt, dctx, scale, MAX_CTX, ws, plan=ops.decode_plan(dctx, hq, hkv, MAX_CTX),
                                    lse=lse0)
-        shp = torch.tensor([2], dtype=torch.int32, device="cuda")
-        plan = ops.decode_plan(dctx, hq, hkv, MAX_CTX, shared_prefix_blocks=shp, block_size=BS)
+        shp = _shp(2, lens, private)
+        plan = ops.decode_plan(dctx, hq, hkv, MAX_CTX, shared_prefix=shp, block_size=BS)
         lse1 = torch.zeros_like(lse0)
         o1 = ops.paged_attn_decode(dq, dk, dv, dbt, dctx, scale, MAX_CTX, torch.zeros_like(ws), plan=plan, lse=lse1)
         torch.cuda.synchronize()
         live = [i for i, n in enumerate(lens) if n > 0]
-        if 1 in lens:
+        if 1 in lens and not private:
             assert torch.equal(o1, o0) and torch.equal(lse1, lse0)
         else:
             assert not torch.equal(o1, o0)
@@ -172,17 +183,17 @@ def test_shared_prefix_count_is_read_when_the_captured_plan_replays(ops):
     dctx, dbt = torch.tensor(lens, dtype=torch.int32).cuda(), bt.cuda()
     scale = 128 ** -0.5
     ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, MAX_CTX), dtype=torch.uint8, device="cuda")
-    shp = torch.tensor([2], dtype=torch.int32, device="cuda")
+    shp = _shp(2, lens)
     plan = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device="cuda")
     out = torch.empty(b, hq, 128, dtype=BF16, device="cuda")
 
     def step():
-        ops.decode_plan(dctx, hq, hkv, MAX_CTX, plan=plan, shared_prefix_blocks=shp, block_size=BS)
+        ops.decode_plan(dctx, hq, hkv, MAX_CTX, plan=plan, shared_prefix=shp, block_size=BS)
         ops.paged_attn_decode_fused(qkv, nw, nw, 1e-6, table, kc, vc, dbt, dctx, hq, scale, MAX_CTX, ws, out=out, plan=plan)
 
     eager = {}
     for n in (2, 0):
-        shp.fill_(n)
+        shp[0] = n
         step()
         torch.cuda.synchronize()
         eager[n] = out.clone()
@@ -191,7 +202,7 @@ def test_shared_prefix_count_is_read_when_the_captured_plan_replays(ops):
     with torch.cuda.graph(graph):
         step()
     for n in (2, 0, 2):
-        shp.fill_(n)
+        shp[0] = n
         out.zero_()
         graph.replay()
         torch.cuda.synchronize()
@@ -202,9 +213,9 @@ def test_shared_prefix_needs_the_matrix_core_kernel_and_aligned_blocks(ops):
     """Hq / Hkv = 1 runs on the packed-dot kernel, which knows nothing of a shared pass; a block size that is not a
     multiple of 128 tokens is refused as well — reported through the error channel, nothing launched."""
     ctx = torch.tensor([600, 700], dtype=torch.int32, device="cuda")
-    shp = torch.tensor([1], dtype=torch.int32, device="cuda")
+    shp = torch.tensor([1, 1, 1], dtype=torch.int32, device="cuda")
     assert not ops.decode_attention_shares_prefixes(8, 8, 256)
     with pytest.raises(ops.NvlError, match="matrix-core"):
-        ops.decode_plan(ctx, 8, 8, MAX_CTX, shared_prefix_blocks=shp, block_size=256)
+        ops.decode_plan(ctx, 8, 8, MAX_CTX, shared_prefix=shp, block_size=256)
     with pytest.raises(ops.NvlError, match="block_size"):
-        ops.decode_plan(ctx, 16, 8, MAX_CTX, shared_prefix_blocks=shp, block_size=96)
+        ops.decode_plan(ctx, 16, 8, MAX_CTX, shared_prefix=shp, block_size=96)

@@ -73,9 +73,9 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
     modulo when the cache is smaller than the pool the schedule was recorded with.
     plan: as the engine does, one nvl_decode_plan per batch (outside the timed bracket: it is one ~4 us launch per
     STEP, not per layer) shared by the L layer launches.
-    shared_blocks_of(bt, lens, n) -> int (the engine's ModelRunner._prefix_blocks_worth_a_pass): batches whose rows all
-    start with the same KV blocks are replayed WITH the shared-prefix pass, as the engine runs them. The bytes such a
-    batch is credited with are the UNIQUE ones — the common blocks once, not once per sequence — so the achieved
+    shared_blocks_of(bt, lens, n) -> (k, member) (the engine's ModelRunner._prefix_group_worth_a_pass): batches in which
+    a group of rows starts with the same KV blocks are replayed WITH the shared-prefix pass, as the engine runs them. The
+    bytes such a batch is credited with are the UNIQUE ones — the common blocks once, not once per member — so the achieved
     rate stays a rate of bytes that had to come from HBM; `per_sequence_bytes_per_launch` is the reference's figure
     (flash_attn_with_kvcache reads every sequence's whole table, layers/attention.py:72-74)."""
     from nano_vllm_amd import ops
@@ -100,9 +100,9 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
         ctx_d = torch.from_numpy(np.ascontiguousarray(ctx)).to(dev)
         bt_d = torch.from_numpy(np.ascontiguousarray(bt)).to(dev)
         q = q_all[:n]
-        shared = int(shared_blocks_of(bt, np.asarray(ctx, dtype=np.int64), n)) if (plan and shared_blocks_of) else 0
-        shp = torch.tensor([shared], dtype=torch.int32, device=dev) if shared > 0 else None
-        step_plan = ops.decode_plan(ctx_d, hq, hkv, max_ctx, shared_prefix_blocks=shp, block_size=block_size) if plan else None
+        shared, member = shared_blocks_of(bt, np.asarray(ctx, dtype=np.int64), n) if (plan and shared_blocks_of) else (0, None)
+        shp = torch.tensor([shared, *member.astype(np.int32).tolist()], dtype=torch.int32, device=dev) if shared > 0 else None
+        step_plan = ops.decode_plan(ctx_d, hq, hkv, max_ctx, shared_prefix=shp, block_size=block_size) if plan else None
 
         def layers():
             for layer in range(L):
@@ -135,7 +135,7 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
         total_ms += start.elapsed_time(stop)
         tok_bytes = 2 * hkv * 128 * kv_cache.element_size() * L
         per_seq_bytes += int(ctx.sum()) * tok_bytes
-        total_bytes += (int(ctx.sum()) - shared * block_size * (n - 1)) * tok_bytes
+        total_bytes += (int(ctx.sum()) - (shared * block_size * (int(member.sum()) - 1) if shared > 0 else 0)) * tok_bytes
         launches += L
         px_launches += L if shared > 0 else 0
     return dict(achieved_GBps=total_bytes / (total_ms * 1e-3) / 1e9, algorithmic_bytes_per_launch=total_bytes / launches,

@@ -42,12 +42,48 @@ px)
   # shared-prefix attention pass: kernel parity, engine parity, config 3 A/B (pass off / on, alternating), headline sanity
   timeout 400 python -m pytest tests/test_shared_prefix_gpu.py -q -rf > $OUT/pytest_px_kernel.log 2>&1; echo "px kernel rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|Error" $OUT/pytest_px_kernel.log | tail -30
   timeout 500 python -m pytest tests/test_e2e_gpu.py -q -rf -s -k "shared_system_prompt or block_edges" > $OUT/pytest_px_e2e.log 2>&1; echo "px e2e rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|shared system|block /" $OUT/pytest_px_e2e.log | cut -c1-400 | tail -20
-  for x in 0 1 0 1; do NVL_SHARED_PREFIX=$x timeout 300 python bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $OUT/cfg3_px$x.json 2> $OUT/cfg3_px$x.err; echo "cfg3 px=$x rc=$?"; tail -c 300 $OUT/cfg3_px$x.err; python -c "
+  for x in old 0 1 old 0 1; do
+    if [ $x = old ]; then (cd _ab_old && timeout 300 python bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $OUT/cfg3_px$x.json 2> $OUT/cfg3_px$x.err)
+    else NVL_SHARED_PREFIX=$x timeout 300 python bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $OUT/cfg3_px$x.json 2> $OUT/cfg3_px$x.err; fi
+    echo "cfg3 px=$x rc=$?"; tail -c 300 $OUT/cfg3_px$x.err | grep -v amdgpu.ids; python -c "
 import json,sys
 d=json.loads([l for l in open('$OUT/cfg3_px$x.json') if l.startswith('{')][-1])
-r=d['roofline']; print('px=$x', round(d['value']), 'tok/s', d['ms_per_step'], 'ms; attn', round(r['avg_launch_us'],1), 'us frac', round(r['frac'],3), 'step', d['config']['decode_ms_per_step_by_batch'], 'px steps', d['config']['decode_step_fusions'].get('decode_steps_with_shared_prefix_pass'))
+r=d['roofline']; print('px=$x', round(d['value']), 'tok/s', round(d['ms_per_step'],1), 'ms; attn', round(r['avg_launch_us'],1), 'us frac', round(r['frac'],3), 'step', d['config']['decode_ms_per_step_by_batch']['ms_per_step'], 'px steps', d['config']['decode_step_fusions'].get('decode_steps_with_shared_prefix_pass'))
 "; cp $OUT/cfg3_px$x.json $OUT/cfg3_px${x}_run_$(date +%s).json; done
-  timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 2 --warmup 1 > $OUT/headline_quick.json 2> $OUT/headline_quick.err; echo "headline rc=$?"; cut -c1-400 $OUT/headline_quick.json;;
+  for x in old new old new; do
+    if [ $x = old ]; then (cd _ab_old && timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 2 --warmup 1 > $OUT/headline_$x.json 2> $OUT/headline_$x.err)
+    else timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 2 --warmup 1 > $OUT/headline_$x.json 2> $OUT/headline_$x.err; fi
+    echo "headline $x rc=$?"; python -c "
+import json
+d=json.loads([l for l in open('$OUT/headline_$x.json') if l.startswith('{')][-1])
+print('$x', round(d['value']), 'tok/s attn', round(d['roofline']['avg_launch_us'],2), d['config']['decode_ms_per_step_by_batch']['ms_per_step'])
+"; cp $OUT/headline_$x.json $OUT/headline_${x}_run_$(date +%s).json; done;;
+px2)
+  # after the prefix kernel's load reorder: kernel parity again, config 3 with the pass (child-style env), and the headline
+  # with / without a small OpenMP pool (the host loop's torch ops)
+  timeout 400 python -m pytest tests/test_shared_prefix_gpu.py -q -rf > $OUT/pytest_px_kernel.log 2>&1; echo "px kernel rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|Error" $OUT/pytest_px_kernel.log | tail -30
+  for x in 1 0 1; do NVL_SHARED_PREFIX=$x OMP_NUM_THREADS=8 timeout 300 python bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $OUT/cfg3_px$x.json 2> $OUT/cfg3_px$x.err; python -c "
+import json
+d=json.loads([l for l in open('$OUT/cfg3_px$x.json') if l.startswith('{')][-1])
+r=d['roofline']; print('px=$x omp8', round(d['value']), 'tok/s; attn', round(r['avg_launch_us'],1), 'us frac', round(r['frac'],3), 'step', d['config']['decode_ms_per_step_by_batch']['ms_per_step'])
+"; cp $OUT/cfg3_px$x.json $OUT/cfg3_px${x}_run_$(date +%s).json; done
+  for x in unset 8 unset 8; do
+    if [ $x = unset ]; then timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 2 --warmup 1 > $OUT/headline_omp$x.json 2> $OUT/headline_omp$x.err
+    else OMP_NUM_THREADS=$x timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 2 --warmup 1 > $OUT/headline_omp$x.json 2> $OUT/headline_omp$x.err; fi
+    python -c "
+import json
+d=json.loads([l for l in open('$OUT/headline_omp$x.json') if l.startswith('{')][-1])
+print('omp=$x', round(d['value']), 'tok/s attn', round(d['roofline']['avg_launch_us'],2), d['config']['decode_ms_per_step_by_batch']['ms_per_step'])
+"; cp $OUT/headline_omp$x.json $OUT/headline_omp${x}_run_$(date +%s).json; done;;
+pxprof)
+  # rocprofv3 kernel stats of config 3 without / with the shared-prefix pass (same box)
+  for x in 0 1; do (cd /tmp && NVL_SHARED_PREFIX=$x OMP_NUM_THREADS=8 timeout 400 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_cfg3_px$x -o cfg3 -- python $REPO/bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $OUT/cfg3_px${x}_under_rocprof.json 2> $OUT/cfg3_px${x}_prof.err; echo "pxprof $x rc=$?")
+    f=$(find /tmp/prof_cfg3_px$x -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/cfg3_px${x}_kernel_stats.csv && head -14 $OUT/cfg3_px${x}_kernel_stats.csv | cut -c1-160
+    python -c "
+import json
+d=json.loads([l for l in open('$OUT/cfg3_px${x}_under_rocprof.json') if l.startswith('{')][-1])
+print('px=$x (under rocprof, OMP 8)', round(d['value']), 'tok/s step', d['config']['decode_ms_per_step_by_batch']['ms_per_step'])
+"; done;;
 cfg3)
   timeout 900 python bench.py --model qwen3-8b --workload prefix --no-cpu-baseline --warmup 0 > $OUT/bench_cfg3_8b_prefix.json 2> $OUT/bench_cfg3.err; echo "cfg3 rc=$?"; tail -c 300 $OUT/bench_cfg3.err; cut -c1-1200 $OUT/bench_cfg3_8b_prefix.json;;
 tpfunc)
