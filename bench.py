@@ -41,6 +41,11 @@ from random import randint, seed
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# a small OpenMP pool for the engine's host loop (before torch is imported): with the default of one thread per logical
+# CPU (256 on the GPU boxes) the pool's spinning workers compete with the HIP runtime's own threads; the extras have
+# always run like this (extra_configs), the headline measures the same either way (gpurun_out r05q: 35.29 / 35.19 k
+# unset vs 35.30 / 35.19 k with 8). The CPU baseline leg sets its own thread count (cpu_baseline_prepare).
+os.environ.setdefault("OMP_NUM_THREADS", "8")
 
 BENCH_T0 = time.perf_counter()      # process start: the extras are budgeted against the whole run's wall time
 REF_4070_LAPTOP_TOKS = 1434.13     # the reference's own number for this workload (other hardware)

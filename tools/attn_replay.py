@@ -30,15 +30,22 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def bench_decode_batches(num_seqs: int = 256, num_blocks: int = 9380, every: int = 8, max_num_seqs: int = 512,
-                         max_num_batched_tokens: int = 16384, block_size: int = 256, max_model_len: int = 4096):
-    """Host-only pass of the bench workload. Returns (samples, stats): samples = list of
+                         max_num_batched_tokens: int = 16384, block_size: int = 256, max_model_len: int = 4096,
+                         kind: str = "bench"):
+    """Host-only pass of the bench workload (`kind` "prefix": BASELINE config 3 — a 512-token system prompt + U[16,256]
+    suffix x 256, 128 output tokens, bench.py::workload). Returns (samples, stats): samples = list of
     (n, ctx int32[n], block_table int32[n, max_blocks]) for every `every`-th decode step."""
     from nano_vllm_amd.api import SamplingParams
     from nano_vllm_amd.engine.sched import Scheduler
     from nano_vllm_amd.engine.seq import Sequence
     seed(0)
-    prompts = [[randint(0, 10000) for _ in range(randint(100, 1024))] for _ in range(num_seqs)]
-    outs = [randint(100, 1024) for _ in range(num_seqs)]
+    if kind == "prefix":
+        system = [randint(0, 10000) for _ in range(512)]
+        prompts = [system + [randint(0, 10000) for _ in range(randint(16, 256))] for _ in range(num_seqs)]
+        outs = [128] * num_seqs
+    else:
+        prompts = [[randint(0, 10000) for _ in range(randint(100, 1024))] for _ in range(num_seqs)]
+        outs = [randint(100, 1024) for _ in range(num_seqs)]
     cfg = SimpleNamespace(max_num_seqs=max_num_seqs, max_num_batched_tokens=max_num_batched_tokens, eos=-1,
                           kvcache_block_size=block_size, num_kvcache_blocks=num_blocks)
     Sequence.block_size = block_size
@@ -158,13 +165,17 @@ def main():
                                                          "captured graph per step (host-bound for short launches)")
     ap.add_argument("--layer-major", action="store_true", help="cache laid out [L, 2, blocks, ...] instead of [2, L, blocks, ...]")
     ap.add_argument("--fp8", action="store_true", help="OCP fp8 e4m3 KV cache (opt-in extension; 128-byte rows)")
+    ap.add_argument("--workload", default="bench", choices=["bench", "prefix"],
+                    help="prefix: BASELINE config 3's schedule (shared 512-token system prompt; use with --hq 32 --hkv 8 --layers 36)")
+    ap.add_argument("--no-shared-prefix", action="store_true",
+                    help="replay batches that share leading KV blocks WITHOUT the shared-prefix pass (the engine's NVL_SHARED_PREFIX=0)")
     ap.add_argument("--cache-blocks", type=int, default=0,
                     help="allocate the cache with this many blocks per layer (like the engine's pool) instead of only the used ones")
     args = ap.parse_args()
     import torch
     from nano_vllm_amd import ops
     ops.load_library()
-    samples, stats = bench_decode_batches(num_blocks=args.pool_blocks, every=args.every)
+    samples, stats = bench_decode_batches(num_blocks=args.pool_blocks, every=args.every, kind=args.workload)
     used = stats["max_block"] + 1
     nblk = max(used, args.cache_blocks)
     dev = torch.device("cuda", 0)
@@ -180,8 +191,19 @@ def main():
             kv8[:, layer, :used] = kv[:, layer, :used].to(torch.float8_e4m3fn)
         kv = kv8
     ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(512, args.hq, 4096), dtype=torch.uint8, device=dev)
+    def group_worth_a_pass(bt, lens, n, min_bytes=32e6):
+        # the engine's decision (ModelRunner._prefix_group_worth_a_pass) for this geometry
+        from nano_vllm_amd.engine.runner import shared_prefix_group
+        k, member = shared_prefix_group(bt[:n], lens, 256)
+        if k == 0:
+            return 0, None
+        m, pack = int(member.sum()), 16 // (args.hq // args.hkv)
+        saved = k * 256 * (m - -(-m // pack)) * args.hkv * 2 * 128 * (1 if args.fp8 else 2)
+        return (k, member) if saved >= min_bytes else (0, None)
+
+    shares = ops.decode_attention_shares_prefixes(args.hq, args.hkv, 256) and not args.no_shared_prefix and not args.no_plan
     r = replay(torch, kv, samples, args.hq, args.hkv, 4096, ws, reps=args.reps, fused=args.fused, plan=not args.no_plan,
-               graph=not args.eager)
+               graph=not args.eager, shared_blocks_of=group_worth_a_pass if shares else None)
     r.update(stats, kernel=f"decode<G={args.hq // args.hkv}, fused={str(args.fused).lower()}, kv={'fp8' if args.fp8 else 'bf16'}>", kv_blocks_used=nblk, samples=len(samples),
              frac_of_8TBps=r["achieved_GBps"] / 8000.0)
     print(json.dumps(r), flush=True)

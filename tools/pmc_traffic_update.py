@@ -20,9 +20,11 @@ rep = json.loads([ln for ln in open(replay).read().splitlines() if ln.startswith
 fetch = {r["kernel"]: r for r in rows if r["counter"] == "FETCH_SIZE"}
 # (template instantiations show up with truncated mangled names: the attention kernel is the row that is neither the
 # split merge nor the per-step plan — and by far the largest)
-main = max((v for k, v in fetch.items() if "combine" not in k and "plan" not in k), key=lambda v: v["mean"])
+main = max((v for k, v in fetch.items() if "combine" not in k and "plan" not in k and "prefix" not in k), key=lambda v: v["mean"])
 comb = next((v for k, v in fetch.items() if "combine" in k), None)
-per_launch_kib = main["mean"] + (comb["mean"] if comb else 0.0)
+# the shared-prefix pass (one more launch per attention call when the label names it): its share of a call's bytes
+pref = next((v for k, v in fetch.items() if "prefix" in k), None) if "prefix" in label else None
+per_launch_kib = main["mean"] + (comb["mean"] if comb else 0.0) + (pref["mean"] * pref["dispatches"] / main["dispatches"] if pref else 0.0)
 hbm = per_launch_kib * 1024 * 2
 alg = rep["algorithmic_bytes_per_launch"]
 path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
@@ -44,7 +46,8 @@ db["kernels"][label] = {
     "source": f"{os.path.basename(summary)} (rocprofv3 --pmc FETCH_SIZE --kernel-include-regex decode_ -- python "
               f"tools/attn_replay.py --fused --reps 1 ...)",
     "model": model, "dispatches": main["dispatches"],
-    "FETCH_SIZE_mean_KiB": {"main": main["mean"], "decode_stream_combine_kernel": comb["mean"] if comb else None},
+    "FETCH_SIZE_mean_KiB": {"main": main["mean"], "decode_stream_combine_kernel": comb["mean"] if comb else None,
+                            **({"decode_prefix_kernel": pref["mean"]} if pref else {})},
     "correction": "x2: on gfx950 FETCH_SIZE reports half the bytes of a 16 B/lane streaming read (MI355X_MICROARCH.md, HBM section)",
     "hbm_read_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": alg, "hbm_read_bytes_over_algorithmic": hbm / alg,
 }
