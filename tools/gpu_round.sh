@@ -165,6 +165,19 @@ pmcg)
     python tools/pmc_traffic_update.py $OUT/pmc_fetch_summary_g$6.json $OUT/replay_under_pmc_g$6.json $5 "decode_mfma8_kernel<fused, bf16 KV, G=$6>"
   done
   cp profiles/pmc_traffic.json $OUT/pmc_traffic.json;;
+pmcpx)
+  # HBM traffic of BASELINE config 3's own schedule (shared system prompt), G = 4: with the shared-prefix pass, and
+  # the same schedule without it
+  cp gpurun_out/r05r/pmc_traffic.json profiles/pmc_traffic.json 2>/dev/null
+  rm -rf /tmp/pmc_g4px /tmp/pmc_g4nopx
+  (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'decode_' -f csv -d /tmp/pmc_g4px -o replay -- python $REPO/tools/attn_replay.py --fused --reps 1 --hq 32 --hkv 8 --layers 36 --every 8 --workload prefix --pool-blocks 6432 > $OUT/replay_under_pmc_g4_prefix.json 2> $OUT/replay_pmc_g4_prefix.err; echo "pmc G=4 prefix rc=$?")
+  python tools/pmc_summary.py /tmp/pmc_g4px $OUT/pmc_fetch_summary_g4_prefix.json > /dev/null
+  python tools/pmc_traffic_update.py $OUT/pmc_fetch_summary_g4_prefix.json $OUT/replay_under_pmc_g4_prefix.json qwen3-8b "decode_prefix_kernel + decode_mfma8_kernel<fused, bf16 KV, G=4>"
+  (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'decode_' -f csv -d /tmp/pmc_g4nopx -o replay -- python $REPO/tools/attn_replay.py --fused --reps 1 --hq 32 --hkv 8 --layers 36 --every 8 --workload prefix --pool-blocks 6432 --no-shared-prefix > $OUT/replay_under_pmc_g4_prefix_pass_off.json 2> $OUT/replay_pmc_g4_prefix_pass_off.err; echo "pmc G=4 prefix, pass off rc=$?")
+  python tools/pmc_summary.py /tmp/pmc_g4nopx $OUT/pmc_fetch_summary_g4_prefix_pass_off.json | tail -8
+  cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
+  # and the kernel durations of the two forms of the same replay
+  for v in "" "--no-shared-prefix"; do (cd /tmp && rm -rf /tmp/prof_px && timeout 300 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_px -o replay -- python $REPO/tools/attn_replay.py --fused --hq 32 --hkv 8 --layers 36 --every 8 --workload prefix --pool-blocks 6432 $v > $OUT/replay_prefix_under_rocprof$v.json 2>/dev/null; f=$(find /tmp/prof_px -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/replay_prefix_kernel_stats$v.csv && grep -i "decode_" $OUT/replay_prefix_kernel_stats$v.csv | cut -c1-140); done;;
 tp3)
   timeout 1500 python -m pytest tests -m gpu -q -rf -s -k "tp or cpu_oracle or fp8_kv_store or rccl or p2p" --durations=8 > $OUT/pytest_tp3.log 2>&1; echo "tp3 pytest rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|argmax|device-resident" $OUT/pytest_tp3.log | tail -30;;
 benchfull)
