@@ -241,7 +241,11 @@ NOTES = {
                      "3200 / 6400, vocabulary / 8 or / 4; add-RMSNorm where the all-reduce would be): an UPPER BOUND per rank, "
                      "not a TP measurement. Fields: value tok/s, ms = ms per pass, attn = roofline.frac of the decode attention "
                      "call, step = decode step frac of 8 TB/s, pf_TF = prefill attention TFLOP/s, kv = KV blocks, wall = seconds "
-                     "incl. engine start. Full child lines: gpurun_out/bench_extras_full.json.",
+                     "incl. engine start. config3 runs the shared-prefix attention pass (prefix-cache blocks shared by a group of "
+                     "rows are read once per pack of 16/G rows): its attn / step are fractions in UNIQUE bytes (shared blocks "
+                     "counted once — round 4's 0.90 / 0.54 were in per-sequence bytes), attn_ps = the same call priced in the "
+                     "reference's per-sequence bytes / 8 TB/s, attn_us = us per attention call. Full child lines: "
+                     "gpurun_out/bench_extras_full.json.",
     "tp_fallback": "a tensor-parallel run whose xGMI P2P collectives latch a spin timeout is re-run with NVL_TP_P2P=0 (process "
                    "group = RCCL) and BOTH attempts are reported; value is never null.",
 }
@@ -450,6 +454,11 @@ def compact_extra(line: dict) -> dict:
            "step": roof.get("decode_step_frac_of_8TBps") and round(roof["decode_step_frac_of_8TBps"], 3),
            "pf_TF": (line.get("roofline_prefill") or {}).get("achieved") and round(line["roofline_prefill"]["achieved"]),
            "kv": (line.get("config") or {}).get("kv_blocks")}
+    if roof.get("launches_with_shared_prefix_pass"):
+        # the shared-prefix pass ran: attn / step are fractions in UNIQUE bytes (shared blocks counted once); attn_ps is the
+        # same call priced in the reference's per-sequence bytes (can exceed 1: those bytes are not read from HBM any more)
+        out["attn_ps"] = round(roof["rate_in_per_sequence_bytes_GBps"] / HBM_PEAK_GBPS, 3)
+        out["attn_us"] = round(roof["avg_launch_us"], 1)
     return {k: v for k, v in out.items() if v is not None}
 
 
