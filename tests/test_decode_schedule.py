@@ -3,14 +3,16 @@ and the attention kernel cut a decode step's (sequence, kv-head, 32-token tile) 
 share segment by segment, and number the split partials. The device code is the authority; this checks, on random
 ragged batches (with graph-padding rows of length 0), the invariants the split workspace and the merge kernel rely on:
 every tile is owned by exactly one wave, a segment's partials get distinct slots 0 .. count-1 with count as the kernel
-writes it into `meta`, and no slot index reaches the `slots` bound the workspace was sized with."""
+writes it into `meta`, and no slot index reaches the `slots` bound the workspace was sized with. With a shared-prefix
+group (nvl_decode_plan's `shared_prefix`): the member rows' leading tiles belong to the shared-prefix pass and nobody else,
+the tile of a member's newest token never does, and the pass's own partial slot (the last one) is never a stream-K slot."""
 import random
 
 K_TILE, K_WAVES, K_MIN_TILES = 32, 4, 4          # kTile, kWaves, kMinTilesPerWave
 
 
 def stream_slots(max_context):                   # inline int stream_slots(int64_t max_context)
-    return max_context // (K_TILE * K_MIN_TILES) + 2
+    return max_context // (K_TILE * K_MIN_TILES) + 3          # (the last slot belongs to the shared-prefix pass)
 
 
 def grid_waves(batch, hkv, max_context, cus=256):     # mfma8_grid(...) * kWaves with a plan (2 workgroups per CU)
@@ -20,9 +22,22 @@ def grid_waves(batch, hkv, max_context, cus=256):     # mfma8_grid(...) * kWaves
     return max(1, min(grid, max_wg)) * K_WAVES
 
 
-def plan(ctx, hkv, nwaves):
+def shared_tiles(ctx, shared_blocks, member, tiles_per_block=8):
+    """decode_plan_kernel's clamp: the pass takes `shared_blocks` blocks of every member, but never the tile that holds a
+    member's newest token: sh <= min over live members of floor((len - 1) / 32); 0 without a live member."""
+    lows = [(n - 1) // K_TILE for n, m in zip(ctx, member) if n > 0 and m]
+    return min(shared_blocks * tiles_per_block, min(lows)) if (lows and shared_blocks > 0) else 0
+
+
+def own_tiles(ctx, sh=0, member=None):
+    """Tiles of every row's OWN share (chunk_prefix with `skip`): all of them, minus the shared ones for a member."""
+    return [max((n + K_TILE - 1) // K_TILE - (sh if (member and member[i]) else 0), 0) if n > 0 else 0
+            for i, n in enumerate(ctx)]
+
+
+def plan(ctx, hkv, nwaves, sh=0, member=None):
     """decode_plan_kernel: header (total, per) + the first segment (b, h, t0, nb) of every wave's share."""
-    nbs = [(n + K_TILE - 1) // K_TILE if n > 0 else 0 for n in ctx]
+    nbs = own_tiles(ctx, sh, member)
     pre = [0]
     for n in nbs:
         pre.append(pre[-1] + n)
@@ -41,9 +56,10 @@ def plan(ctx, hkv, nwaves):
     return total, per, ents, pre
 
 
-def walk(ctx, hkv, total, per, ents):
-    """decode_mfma8_kernel's share loop: yields (wave, b, h, first tile, tiles, partial slot k, partial count written)."""
-    nbs = [(n + K_TILE - 1) // K_TILE if n > 0 else 0 for n in ctx]
+def walk(ctx, hkv, total, per, ents, sh=0, member=None):
+    """decode_mfma8_kernel's share loop: yields (wave, b, h, first tile, tiles, partial slot k, partial count written);
+    tile indices are relative to the row's OWN share (tile t of the share is tile t + sh of a member's sequence)."""
+    nbs = own_tiles(ctx, sh, member)
     for wid, e in enumerate(ents):
         if e is None:
             continue
@@ -83,7 +99,7 @@ def test_every_tile_has_one_owner_and_partials_fit_their_slots():
         slots = stream_slots(max_context)
         owner, parts = {}, {}
         for wid, b, h, t0, run, k, count in walk(ctx, hkv, total, per, ents):
-            assert 0 <= k < slots, (k, slots, ctx[b], per)
+            assert 0 <= k < slots - 1, (k, slots, ctx[b], per)
             for t in range(t0, t0 + run):
                 assert (b, h, t) not in owner
                 owner[(b, h, t)] = wid
@@ -93,3 +109,39 @@ def test_every_tile_has_one_owner_and_partials_fit_their_slots():
         for (b, h), kc in parts.items():
             ks, counts = [k for k, _ in kc], {c for _, c in kc}
             assert len(counts) == 1 and sorted(ks) == list(range(counts.pop())), (b, h, kc)
+
+
+def test_shared_prefix_group_splits_the_tiles_between_the_pass_and_the_stream_k_shares():
+    rng = random.Random(5)
+    seen_clamp = seen_full = 0
+    for trial in range(80):
+        batch = rng.choice([2, 7, 64, 131, 256])
+        hkv = rng.choice([1, 2, 8])
+        max_context = rng.choice([2048, 4096, 16384])
+        blocks = rng.choice([1, 2, 5])
+        ctx = [0 if rng.random() < 0.1 else rng.randint(1, max_context) for _ in range(batch)]
+        member = [rng.random() < 0.8 for _ in range(batch)]          # (padding rows may carry a stale flag)
+        if trial % 3:                                                # mostly: members really are longer than the shared blocks
+            ctx = [max(n, blocks * 256 + rng.randint(1, 40)) if (n and m) else n for n, m in zip(ctx, member)]
+        if not any(n and m for n, m in zip(ctx, member)):
+            continue
+        sh = shared_tiles(ctx, blocks, member)
+        seen_clamp += sh < blocks * 8
+        seen_full += sh == blocks * 8
+        nwaves = grid_waves(batch, hkv, max_context, cus=rng.choice([8, 64, 256]))
+        total, per, ents, pre = plan(ctx, hkv, nwaves, sh, member)
+        slots = stream_slots(max_context)
+        owner = {}
+        for wid, b, h, t0, run, k, count in walk(ctx, hkv, total, per, ents, sh, member):
+            assert 0 <= k < slots - 1                                 # slot slots - 1 is the pass's
+            off = sh if member[b] else 0
+            for t in range(t0 + off, t0 + off + run):
+                assert (b, h, t) not in owner
+                owner[(b, h, t)] = wid
+        passed = {(b, h, t) for b, n in enumerate(ctx) if n > 0 and member[b] for h in range(hkv) for t in range(sh)}
+        want = {(b, h, t) for b, n in enumerate(ctx) for h in range(hkv) for t in range((n + K_TILE - 1) // K_TILE if n else 0)}
+        assert not (set(owner) & passed) and set(owner) | passed == want
+        for b, n in enumerate(ctx):                                   # the newest token's tile is always the row's own
+            if n > 0:
+                assert all((b, h, (n - 1) // K_TILE) in owner for h in range(hkv))
+    assert seen_clamp and seen_full
