@@ -206,6 +206,36 @@ def test_tp2_engine_greedy_parity_on_one_gpu(tiny_ckpt, mode, monkeypatch):
 
 
 @pytest.mark.timeout(900)
+def test_tp2_engine_shared_system_prompt_takes_the_shared_prefix_pass_on_every_rank(tiny_ckpt, monkeypatch):
+    """The shared-prefix attention pass under tensor parallelism: rank 0 finds the group of rows that share their leading
+    KV blocks and ships it inside the staging image; EVERY rank decides from that image, captures the bucket's graph with
+    the pass at the same step (P2P collectives inside) and replays it — per rank 2 query heads on 1 kv head (packs of 8
+    rows). Tokens, batches and block tables judged against the oracle engine; greedy and sampled rows in one batch."""
+    from test_e2e_gpu import _check, _judge, _run_ours
+    monkeypatch.setenv("NVL_TP_SHARE_GPU", "1")
+    monkeypatch.setenv("NVL_TP_BACKEND", "gloo")
+    monkeypatch.setenv("NVL_TP_PORT", str(_free_port()))
+    monkeypatch.setenv("NVL_TP_P2P", "1")
+    monkeypatch.setenv("NVL_TP_P2P_STRESS_EPOCHS", "100")
+    monkeypatch.setenv("NVL_SHARED_PREFIX_MIN_MB", "0")
+    g = torch.Generator().manual_seed(131)
+    shared = torch.randint(0, 512, (520,), generator=g).tolist()
+    prompts = [shared + torch.randint(0, 512, (int(n),), generator=g).tolist() for n in (3, 40, 150, 9, 220, 61)]
+    prompts.insert(2, torch.randint(0, 512, (300,), generator=g).tolist())
+    max_tokens = [30, 14, 5, 30, 21, 30, 9]
+    temps = [0.0, 0.6, 0.0, 0.0, 0.0, 0.9, 0.0]
+    info = {}
+    outs, rec, nblk = _run_ours(tiny_ckpt, prompts, max_tokens, temperatures=temps, info=info, enforce_eager=False,
+                                max_model_len=2048, num_kvcache_blocks=32, max_num_seqs=16, max_num_batched_tokens=1536,
+                                tensor_parallel_size=2, seed=9)
+    assert [len(o["token_ids"]) for o in outs] == max_tokens
+    assert info["prefix_steps"] > 0 and len(info["prefix_graphs"]) >= 1, info
+    _check("tiny TP=2 p2p-graph, shared system prompt",
+           _judge(tiny_ckpt, prompts, max_tokens, rec, nblk, temperatures=temps, seed=9, max_num_seqs=16,
+                  max_num_batched_tokens=1536), sum(max_tokens))
+
+
+@pytest.mark.timeout(900)
 def test_tp2_engine_sampled_T06_parity_draws_replayed_on_one_gpu(tiny_ckpt, monkeypatch):
     """T > 0 at TP = 2 inside the captured decode graph: each rank races ITS vocabulary shard (Philox keyed by the GLOBAL
     column), 8 bytes per row are exchanged, every rank merges — the merged token must be the argmax of `l/T - log E`

@@ -39,10 +39,13 @@ fp8)
   timeout 900 python -m pytest tests -m gpu -q -rf -k "fp8" > $OUT/pytest_fp8.log 2>&1; echo "fp8 tests rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|fp8 KV vs" $OUT/pytest_fp8.log | tail -12
   timeout 600 python bench.py --kv-cache-dtype fp8 --no-cpu-baseline > $OUT/bench_fp8kv.json 2> $OUT/bench_fp8kv.err; echo "bench fp8 rc=$?"; tail -c 400 $OUT/bench_fp8kv.err; cut -c1-1500 $OUT/bench_fp8kv.json;;
 px)
-  # shared-prefix attention pass: kernel parity, engine parity, config 3 A/B (pass off / on, alternating), headline sanity
+  # shared-prefix attention pass: kernel parity, engine parity, config 3 A/B (pass off / on, alternating), headline sanity.
+  # "old" = another commit's tree built in a worktree next to this one (git worktree add -f _ab_old <commit>; build() there):
+  # skipped when it is not there
   timeout 400 python -m pytest tests/test_shared_prefix_gpu.py -q -rf > $OUT/pytest_px_kernel.log 2>&1; echo "px kernel rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|Error" $OUT/pytest_px_kernel.log | tail -30
   timeout 500 python -m pytest tests/test_e2e_gpu.py -q -rf -s -k "shared_system_prompt or block_edges" > $OUT/pytest_px_e2e.log 2>&1; echo "px e2e rc=$?"; grep -E "^(FAILED|ERROR)|passed|failed|shared system|block /" $OUT/pytest_px_e2e.log | cut -c1-400 | tail -20
   for x in old 0 1 old 0 1; do
+    [ $x = old ] && [ ! -d _ab_old ] && continue
     if [ $x = old ]; then (cd _ab_old && timeout 300 python bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $OUT/cfg3_px$x.json 2> $OUT/cfg3_px$x.err)
     else NVL_SHARED_PREFIX=$x timeout 300 python bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $OUT/cfg3_px$x.json 2> $OUT/cfg3_px$x.err; fi
     echo "cfg3 px=$x rc=$?"; tail -c 300 $OUT/cfg3_px$x.err | grep -v amdgpu.ids; python -c "
@@ -51,6 +54,7 @@ d=json.loads([l for l in open('$OUT/cfg3_px$x.json') if l.startswith('{')][-1])
 r=d['roofline']; print('px=$x', round(d['value']), 'tok/s', round(d['ms_per_step'],1), 'ms; attn', round(r['avg_launch_us'],1), 'us frac', round(r['frac'],3), 'step', d['config']['decode_ms_per_step_by_batch']['ms_per_step'], 'px steps', d['config']['decode_step_fusions'].get('decode_steps_with_shared_prefix_pass'))
 "; cp $OUT/cfg3_px$x.json $OUT/cfg3_px${x}_run_$(date +%s).json; done
   for x in old new old new; do
+    [ $x = old ] && [ ! -d _ab_old ] && continue
     if [ $x = old ]; then (cd _ab_old && timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 2 --warmup 1 > $OUT/headline_$x.json 2> $OUT/headline_$x.err)
     else timeout 300 python bench.py --no-cpu-baseline --no-extra-configs --steps 2 --warmup 1 > $OUT/headline_$x.json 2> $OUT/headline_$x.err; fi
     echo "headline $x rc=$?"; python -c "
