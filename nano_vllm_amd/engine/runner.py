@@ -456,11 +456,15 @@ class ModelRunner:
         # same KV blocks (prefix-cache hits on one system prompt) reads them once per pack of 16 / G sequences. It is one
         # more launch per layer, so a step takes it only when the K/V bytes it saves are worth that (prepare_decode);
         # the graph of a bucket WITH the pass is captured the first time a step of that bucket wants it.
-        # NVL_SHARED_PREFIX=0 switches it off; NVL_SHARED_PREFIX_MIN_MB sets the threshold (saved MB per layer).
+        # NVL_SHARED_PREFIX=0 switches it off; NVL_SHARED_PREFIX_MIN_MB sets the threshold (saved MB per layer). The
+        # default is the measured break-even (profiles/r05_shared_prefix_crossover.json: config 3's workload at 48 / 96 /
+        # 160 / 256 sequences, 0.6B and 8B shapes: -16 / -3 / +7 / +13 % and -6 / -1 / +2 / +4.5 % tok/s with the pass on;
+        # zero crossing at 145-160 MB): the pass is a ~17 us latency-bound launch per layer and shortens the stream-K
+        # shares, and at small batches L2 / Infinity Cache already absorb most of the repeated reads.
         self.share_prefix = (self.use_plan and os.environ.get("NVL_SHARED_PREFIX", "1") != "0"
                              and ops.decode_attention_shares_prefixes(self.geo["heads"], self.geo["kv_heads"],
                                                                       self.block_size))
-        self.share_prefix_min_bytes = float(os.environ.get("NVL_SHARED_PREFIX_MIN_MB", "32")) * 1e6
+        self.share_prefix_min_bytes = float(os.environ.get("NVL_SHARED_PREFIX_MIN_MB", "160")) * 1e6
         self.decode_plan_px = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
         self.graphs_px: dict[int, torch.cuda.CUDAGraph] = {}
         self.prefix_steps = 0                # decode steps that ran the shared-prefix pass (reporting)

@@ -191,7 +191,7 @@ def main():
             kv8[:, layer, :used] = kv[:, layer, :used].to(torch.float8_e4m3fn)
         kv = kv8
     ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(512, args.hq, 4096), dtype=torch.uint8, device=dev)
-    def group_worth_a_pass(bt, lens, n, min_bytes=32e6):
+    def group_worth_a_pass(bt, lens, n, min_bytes=160e6):
         # the engine's decision (ModelRunner._prefix_group_worth_a_pass) for this geometry
         from nano_vllm_amd.engine.runner import shared_prefix_group
         k, member = shared_prefix_group(bt[:n], lens, 256)
