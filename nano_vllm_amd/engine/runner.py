@@ -452,8 +452,8 @@ class ModelRunner:
         # its own schedule again (A/B measurements)
         self.use_plan = os.environ.get("NVL_DECODE_PLAN", "1") != "0"
         self.decode_plan = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
-        # shared-prefix attention pass (include/nvl.h, nvl_decode_plan): a decode step whose sequences all start with the
-        # same KV blocks (prefix-cache hits on one system prompt) reads them once per pack of 16 / G sequences. It is one
+        # shared-prefix attention pass (include/nvl.h, nvl_decode_plan): a decode step in which a group of sequences starts
+        # with the same KV blocks (prefix-cache hits on one system prompt) reads them once per pack of 16 / G rows. It is one
         # more launch per layer, so a step takes it only when the K/V bytes it saves are worth that (prepare_decode);
         # the graph of a bucket WITH the pass is captured the first time a step of that bucket wants it.
         # NVL_SHARED_PREFIX=0 switches it off; NVL_SHARED_PREFIX_MIN_MB sets the threshold (saved MB per layer). The
