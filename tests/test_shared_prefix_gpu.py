@@ -126,6 +126,47 @@ def test_fused_decode_with_a_shared_prefix_pass(ops, hq, hkv, shared, kv):
 
 
 @pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1)])
+@pytest.mark.parametrize("splits", [2, 5])
+def test_shared_prefix_pass_on_qkv_split_k_slabs(ops, hq, hkv, splits):
+    """The deep-K models hand the fused decode attention their qkv projection as fp32 split-K slabs (Qwen3-8B in BASELINE
+    config 3 does, at the batch sizes whose GEMM plan splits K): the pass kernel's q prologue sums them with the same
+    helper as the stream-K kernel's — output, LSE and both caches are bit-identical to the launch on the reduced bf16
+    matrix, with the shared-prefix pass running in both."""
+    gen = g(330 + splits)
+    b = len(LENS)
+    bt, total = _tables(LENS, 2, gen, PRIVATE)
+    kc = (torch.randn(total, hkv, BS, 128, generator=gen) * 0.7).to(BF16)
+    vc = (torch.randn(total, hkv, BS, 128, generator=gen) * 0.7).to(BF16)
+    slabs = (torch.randn(splits, b, (hq + 2 * hkv) * 128, generator=gen) / splits ** 0.5).cuda()
+    acc = slabs[0].clone()
+    for s_ in range(1, splits):
+        acc += slabs[s_]                                   # fp32, slab order: what the slab-reduce launch would write
+    qkv = acc.to(BF16)
+    qw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16).cuda()
+    kw = (1 + 0.1 * torch.randn(128, generator=gen)).to(BF16).cuda()
+    table = _rope_table().cuda()
+    dctx, dbt = torch.tensor(LENS, dtype=torch.int32).cuda(), bt.cuda()
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, MAX_CTX), dtype=torch.uint8, device="cuda")
+    shp = _shp(2, LENS, PRIVATE)
+    outs = []
+    for src in (qkv, slabs):
+        k1, v1 = kc.clone().cuda(), vc.clone().cuda()
+        lse = torch.zeros(b, hq, dtype=torch.float32, device="cuda")
+        plan = ops.decode_plan(dctx, hq, hkv, MAX_CTX, shared_prefix=shp, block_size=BS)
+        o = ops.paged_attn_decode_fused(src, qw, kw, 1e-6, table, k1, v1, dbt, dctx, hq, 128 ** -0.5, MAX_CTX,
+                                        torch.zeros_like(ws), plan=plan, lse=lse)
+        torch.cuda.synchronize()
+        outs.append((o, lse, k1, v1))
+    assert all(torch.equal(a, c) for a, c in zip(outs[0], outs[1]))
+    # ... and the pass really ran on the slabs: the plain launch on the same slabs differs in the summation order
+    k1, v1 = kc.clone().cuda(), vc.clone().cuda()
+    o_plain = ops.paged_attn_decode_fused(slabs, qw, kw, 1e-6, table, k1, v1, dbt, dctx, hq, 128 ** -0.5, MAX_CTX,
+                                          torch.zeros_like(ws), plan=ops.decode_plan(dctx, hq, hkv, MAX_CTX))
+    assert not torch.equal(o_plain, outs[1][0])
+    assert float((o_plain.float() - outs[1][0].float()).abs().max()) <= 1e-2 * float(o_plain.float().abs().max())
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1)])
 def test_unfused_decode_clamps_the_shared_prefix_to_the_shortest_row(ops, hq, hkv):
     """nvl_paged_attn_decode (K/V already stored) with two common blocks claimed while one member ends INSIDE the second
     one (500 tokens: its tail is the common block's content) and one is a single token: the device clamps the pass to
