@@ -461,7 +461,11 @@ class ModelRunner:
         # 160 / 256 sequences, 0.6B and 8B shapes: -16 / -3 / +7 / +13 % and -6 / -1 / +2 / +4.5 % tok/s with the pass on;
         # zero crossing at 145-160 MB): the pass is a ~17 us latency-bound launch per layer and shortens the stream-K
         # shares, and at small batches L2 / Infinity Cache already absorb most of the repeated reads.
-        self.share_prefix = (self.use_plan and os.environ.get("NVL_SHARED_PREFIX", "1") != "0"
+        # With the opt-in fp8 KV cache the pass is OFF unless NVL_SHARED_PREFIX=1 asks for it: half the bytes to save, the
+        # same latency chain plus the fp8 -> bf16 conversion of every shared tile per pack — config 3's workload on the
+        # 0.6B shapes, 256 sequences: 63.99 k tok/s without vs 60.59 k with the pass (gpurun_out r05z).
+        fp8_kv = cfg.kv_cache_dtype == "fp8"
+        self.share_prefix = (self.use_plan and os.environ.get("NVL_SHARED_PREFIX", "0" if fp8_kv else "1") != "0"
                              and ops.decode_attention_shares_prefixes(self.geo["heads"], self.geo["kv_heads"],
                                                                       self.block_size))
         self.share_prefix_min_bytes = float(os.environ.get("NVL_SHARED_PREFIX_MIN_MB", "160")) * 1e6
