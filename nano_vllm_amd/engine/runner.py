@@ -436,6 +436,7 @@ class ModelRunner:
         ], self.device)
         self.step_count = 0
         self.share_prefix = False            # (decided below, once the device side exists)
+        self._seen_cached_kv = False         # has any prefill step attended to K/V it did not compute itself?
         self._inflight: list = []            # decode steps enqueued and not yet collected (at most two)
         self._flight_parity = 0
         self._last_rows: dict = {}
@@ -560,6 +561,7 @@ class ModelRunner:
         ns = len(seqs)
         paged = int(cu_k[ns]) > int(cu_q[ns])                  # some K/V must come from the cache
         if paged:
+            self._seen_cached_kv = True                        # (prefix-cache hits or chunked prefill: blocks MAY be shared)
             bt = st["bt"]
             for i, seq in enumerate(seqs):
                 t = seq.block_table
@@ -607,7 +609,9 @@ class ModelRunner:
             bt[i, len(t):] = -1
         key[:n, 0], key[:n, 1], key[:n, 2] = ids, nblk, gen
         # shared-prefix pass: [0] = leading blocks the member rows have in common (0: plain step), [1 + row] = member
-        k, member = self._prefix_group_worth_a_pass(bt, lens, n) if self.share_prefix else (0, None)
+        # (two rows can only hold the same block when a prefill step took K/V from the cache: a run that never did —
+        #  the headline workload — skips the search)
+        k, member = self._prefix_group_worth_a_pass(bt, lens, n) if (self.share_prefix and self._seen_cached_kv) else (0, None)
         st["shp"][0] = k
         if k > 0:
             st["shp"][1:1 + n] = member
