@@ -719,7 +719,7 @@ def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
     achieved = r["achieved_GBps"]
     # the kernel nvl_paged_attn_decode_fused dispatches to for this geometry (attn_decode.hip: decode_common)
     G, fp8 = hq // hkv, runner.kv_cache.element_size() == 1
-    if G == 8 or (G in (2, 4) and os.environ.get("NVL_DECODE_MFMA", "1") != "0"):
+    if G == 8 or (G in (2, 4) and os.environ.get("NVL_DECODE_MFMA", "1") != "0") or (G > 1 and G not in (2, 4)):
         kernel = f"decode_mfma8_kernel<fused, {'fp8' if fp8 else 'bf16'} KV, G={G}>"
     else:
         kernel = f"decode_stream_fp8_kernel<{G}, fused>" if fp8 else f"decode_stream_kernel<{G}, fused>"

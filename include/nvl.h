@@ -197,6 +197,8 @@ int nvl_qknorm_rope_kvstore(const void* qkv, int64_t qkv_tok_stride,
  * P rounded to bf16 before P.V, bf16 output. Rows with context_lens[b] == 0
  * (graph padding, engine/model_runner.py:208) produce zeros.
  * q: [batch, Hq, 128] contiguous; out: [batch, Hq, 128] contiguous.
+ * Any group size Hq/Hkv from 1 to 16 (models/qwen3.py:29-38 takes any ratio:
+ * Qwen3-14B is 40 / 8 = 5, at every TP degree); larger ones return NVL_EINVAL.
  * block_tables: [batch, bt_stride] int32, entries past the context unused
  * (-1 padded, engine/model_runner.py:125). HBM-bound: reads
  * context_len * 2 * Hkv * 256 bytes per sequence.
@@ -239,12 +241,12 @@ int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
  *   with the same prompt prefix (engine/block_manager.py:58-82 hands a cache hit the block id of the earlier request;
  *   requests prefilled before the first one was registered, :110-120, hold private copies and are not members).
  *   A plan built with it makes the attention calls that consume it run a SHARED-PREFIX PASS: those blocks are read
- *   once per pack of 16 / (Hq/Hkv) consecutive sequences instead of once per member, and the per-sequence kernel
+ *   once per pack of floor(16 / (Hq/Hkv)) consecutive sequences instead of once per member, and the per-sequence kernel
  *   starts a member behind them; results are merged like any split (same value up to the fp32 summation order).
  *   The array is read on the device when the plan kernel AND the attention kernels run (graph replays see the current
  *   values; it must stay valid as long as the plan is used, like context_lens). [0] = 0: no shared prefix, the pass
  *   is a no-op. The count is clamped so that the tile holding a member's newest token always stays in that
- *   sequence's own share. Needs the matrix-core decode kernel (Hq/Hkv in {2, 4, 8}) and block_size % 128 == 0
+ *   sequence's own share. Needs the matrix-core decode kernel (Hq/Hkv in 2 ... 16) and block_size % 128 == 0
  *   (`block_size` is only read when shared_prefix != NULL). Whether the pass is launched is a property of the plan
  *   BUFFER (remembered like its geometry): re-plan the same buffer without the pointer to switch it off. */
 size_t nvl_decode_plan_bytes(void);
@@ -283,7 +285,7 @@ int nvl_paged_attn_decode_fused(const void* qkv, int64_t qkv_tok_stride,
  * (slab s at element offset s * qkv_split_stride): the attention prologue sums a row piece over the
  * slabs in slab order and rounds it to bf16 once — the value the separate slab-reduce launch would
  * have produced, bit for bit — before the norm / rotation. Matrix-core kernel only (Hq / Hkv in
- * {2, 4, 8}); other group sizes return NVL_EUNSUPPORTED. */
+ * 2 ... 16; group size 1 returns NVL_EUNSUPPORTED). */
 
 /* ---- Varlen causal prefill attention (MFMA) ----------------------------------
  * Replaces flash_attn_varlen_func as called at layers/attention.py:67-70:
@@ -400,6 +402,12 @@ int nvl_allreduce_add_rmsnorm(void* comm, const void* x_partial, void* residual,
                               void* y, int64_t rows, int hidden, float eps, void* stream);
 int nvl_allreduce_gather(void* comm, const void* in, void* out, int64_t bytes_per_rank, void* stream);
 int nvl_allreduce_status(void* comm);
+/* status_async (ABI 6): enqueue-only form for the serving path — one tiny kernel writes into *status_out (uint32 in
+ * DEVICE memory) whether ANY rank of the group has latched a spin timeout so far (every rank's flag region is mapped
+ * on every rank). Capturable: the engine puts it at the end of every decode step and copies the word to the host with
+ * the step's sampled ids, so a timed-out collective raises from step() / generate() instead of returning the garbage
+ * tokens that followed it (the reference's dist.all_reduce, layers/linear.py:153-156, would hang or raise in NCCL). */
+int nvl_allreduce_status_async(void* comm, void* status_out, void* stream);
 int nvl_allreduce_destroy(void* comm);
 
 /* Host-side reference of the sampler's RNG (same Philox stream as the

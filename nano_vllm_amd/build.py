@@ -20,6 +20,8 @@ LIB = os.path.join(LIBDIR, "libnvl_hip.so")
 STAMP = os.path.join(LIBDIR, "libnvl_hip.stamp")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
+if os.environ.get("NVL_PROBES") == "1":       # probe build: the kernels' measurement switches (NVL_WIDE_DBG / _DEBUG) exist
+    FLAGS.append("-DNVL_PROBES")
 
 
 def _hipcc() -> str:

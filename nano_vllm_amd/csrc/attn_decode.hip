@@ -710,8 +710,17 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
     int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
     int* __restrict__ meta, bf16_t* __restrict__ out, int batch, int hkv, int block_size, int slots,
-    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan) {
-  static_assert(G >= 1 && G <= 8, "one 16-column MFMA tile holds the heads of a kv group (padded with zero columns)");
+    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan, int g_rt) {
+  // G = 0: the group size is the runtime argument g_rt (1 ... 16; Qwen3-14B is 40 / 8 = 5) — one instantiation serves every
+  // group size without a tuned one; the heads still fill ONE 16-column MFMA tile, padded with zero columns
+  static_assert(G >= 0 && G <= 16, "one 16-column MFMA tile holds the heads of a kv group (padded with zero columns)");
+  int Gv = G;
+  if constexpr (G == 0) {
+    // (kept in a VECTOR register: the kernel sits at its scalar-register limit, and every use of the group size — head
+    //  offsets, column masks — is per-lane arithmetic anyway)
+    asm volatile("v_mov_b32 %0, %1" : "=v"(Gv) : "s"(g_rt));
+  }
+  constexpr int NIT = (G > 0 && G <= 8) ? 2 : 4;          // prologue passes: 4 head rows per pass
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int* wsum = reinterpret_cast<int*>(smem_raw + kWaves * kMWaveLds);
   int* pre = wsum + kWaves;  // tile prefix [batch + 1]
@@ -719,7 +728,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane & 15, rq = lane >> 4;      // load / prologue view: 16 lanes x 8 dims = one row
   const int head = lane & 15, quad = lane >> 4;   // MFMA view: one head column per lane
-  const int hq = hkv * G;
+  const int hq = hkv * Gv;
   unsigned char* k_lds = smem_raw + wave * kMWaveLds;
   unsigned char* v_lds = k_lds + kTile * kMKRow;
 
@@ -872,16 +881,20 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
           wk = *reinterpret_cast<const u32x4_t*>(fa.k_norm_w + sub * 8);
         }
       }
-      u32x4_t qh[2];
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        qh[it] = u32x4_t{0u, 0u, 0u, 0u};
-        if (rq + 4 * it < G) {
-          if constexpr (FUSED) qh[it] = load_qkv8<SLABS>(q, row_e + (h * G + rq + 4 * it) * 128 + sub * 8, fa);
-          else qh[it] = *reinterpret_cast<const u32x4_t*>(row + (h * G + rq + 4 * it) * 128 + sub * 8);
+      // (runtime group size: the passes run as a rolled loop and the new token's scores re-read q from the staging tile —
+      //  four unrolled passes push the kernel past its scalar-register limit)
+      constexpr int kUnroll = G == 0 ? 1 : NIT;
+      u32x4_t qh[kUnroll];
+#pragma unroll kUnroll
+      for (int it = 0; it < NIT; ++it) {
+        u32x4_t& qq = qh[G == 0 ? 0 : it];
+        qq = u32x4_t{0u, 0u, 0u, 0u};
+        if (rq + 4 * it < Gv) {
+          if constexpr (FUSED) qq = load_qkv8<SLABS>(q, row_e + (h * Gv + rq + 4 * it) * 128 + sub * 8, fa);
+          else qq = *reinterpret_cast<const u32x4_t*>(row + (h * Gv + rq + 4 * it) * 128 + sub * 8);
         }
-        if constexpr (FUSED) qh[it] = norm_rope_head_regs(qh[it], fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
-        *reinterpret_cast<u32x4_t*>(k_lds + (rq + 4 * it) * 256 + sub * 16) = qh[it];   // q tile [8 heads][128]
+        if constexpr (FUSED) qq = norm_rope_head_regs(qq, fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
+        *reinterpret_cast<u32x4_t*>(k_lds + (rq + 4 * it) * 256 + sub * 16) = qq;      // q tile [8 or 16 heads][128]
       }
       if constexpr (FUSED) {
         if (owns_last) {
@@ -913,9 +926,10 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
             *reinterpret_cast<u32x4_t*>(v_lds + sub * 16) = vnew;                      // v row for the O init
           }
           // scores of the new token against the 8 heads, via the same staging region
-#pragma unroll
-          for (int it = 0; it < 2; ++it) {
-            const float sn = row16_allreduce_sum(dot8(knew, qh[it]));
+#pragma unroll kUnroll
+          for (int it = 0; it < NIT; ++it) {
+            const u32x4_t qq = G == 0 ? *reinterpret_cast<const u32x4_t*>(k_lds + (rq + 4 * it) * 256 + sub * 16) : qh[G == 0 ? 0 : it];
+            const float sn = row16_allreduce_sum(dot8(knew, qq));
             if (sub == 0) *reinterpret_cast<float*>(v_lds + 256 + (rq + 4 * it) * 4) = sn;
           }
         }
@@ -926,14 +940,14 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       u32x4_t w = {0u, 0u, 0u, 0u};
-      if (head < G) w = *reinterpret_cast<const u32x4_t*>(k_lds + head * 256 + (4 * c + quad) * 16);
+      if (head < Gv) w = *reinterpret_cast<const u32x4_t*>(k_lds + head * 256 + (4 * c + quad) * 16);
       qb[c] = __builtin_bit_cast(bf16x8_t, w);
     }
     if constexpr (FUSED) {
       if (owns_last) {
         // The new token enters the online softmax as the first key of this wave's segment (m = its score,
         // l = 1 counted once per head, O = v): its cache row is never read back inside this launch.
-        m_run = *reinterpret_cast<const float*>(v_lds + 256 + (head & 7) * 4) * scale_log2e;
+        m_run = *reinterpret_cast<const float*>(v_lds + 256 + (head & (4 * NIT - 1)) * 4) * scale_log2e;
         l_run = quad == 0 ? 1.f : 0.f;
 #pragma unroll
         for (int db = 0; db < 8; ++db) {
@@ -1045,8 +1059,8 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     const int k = (int)(wid - first);
     l_run += __shfl_xor(l_run, 16, 64);
     l_run += __shfl_xor(l_run, 32, 64);
-    if (head < G) {
-      const int64_t pidx = ((int64_t)b * hq + h * G + head) * slots + k;
+    if (head < Gv) {
+      const int64_t pidx = ((int64_t)b * hq + h * Gv + head) * slots + k;
       float* dst = part_o + pidx * 128 + 4 * quad;
 #pragma unroll
       for (int db = 0; db < 8; ++db) *reinterpret_cast<f32x4_t*>(dst + 16 * db) = oacc[db];
@@ -1080,9 +1094,12 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, const int32_t* __restrict__ ctx,
     float* __restrict__ part_o, float* __restrict__ part_ml, int batch, int hkv, int block_size, int slots,
-    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan) {
-  static_assert(G == 2 || G == 4 || G == 8, "a pack fills the 16 MFMA columns with 16 / G sequences");
-  constexpr int P = 16 / G;
+    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan, int g_rt) {
+  // a pack fills the 16 MFMA columns with P = floor(16 / G) sequences; columns P G .. 15 (group sizes that do not divide 16)
+  // are zero padding. G = 0: runtime group size g_rt, as in decode_mfma8_kernel
+  static_assert(G >= 0 && G <= 16, "a pack fills the 16 MFMA columns with floor(16 / G) sequences");
+  const int Gv = G > 0 ? G : g_rt;
+  const int P = 16 / Gv;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int sh = plan->sh_tiles;
   if (sh <= 0 || plan->batch != batch || plan->hkv != hkv) return;          // (workgroup-uniform)
@@ -1090,12 +1107,11 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane & 15, rq = lane >> 4;      // prologue view: 16 lanes x 8 dims = one row
   const int col = lane & 15, quad = lane >> 4;    // MFMA view: one (sequence, head) column per lane
-  const int hq = hkv * G;
+  const int hq = hkv * Gv;
   const int pack = blockIdx.x / hkv, h = blockIdx.x - pack * hkv;
   const int b0 = pack * P;
   // the block-table row the prefix tiles are looked up in: the pack's first live member (all members agree on them)
   int tb = -1;
-#pragma unroll
   for (int j = P - 1; j >= 0; --j) {
     const int bj = b0 + j;
     if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0 && __builtin_amdgcn_readfirstlane(member[bj]) != 0) tb = bj;
@@ -1147,19 +1163,19 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
       const int r = rq + 4 * it;
-      const int seq = b0 + r / G, hd = r % G;
+      const int seq = b0 + r / Gv, hd = r % Gv;
       const int seq_c = seq < batch ? seq : batch - 1;
       const int len = ctx[seq_c];
-      const bool live = seq < batch && len > 0 && member[seq_c] != 0;
+      const bool live = r < P * Gv && seq < batch && len > 0 && member[seq_c] != 0;
       u32x4_t qh;
       if constexpr (FUSED) {
         int64_t pos = len > 0 ? len - 1 : 0;
         pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
         const RopeRegs rr = load_rope_regs(fa.cos_sin + pos * 128, sub);
-        qh = load_qkv8<SLABS>(q, (int64_t)seq_c * fa.qkv_tok_stride + (h * G + hd) * 128 + sub * 8, fa);
+        qh = load_qkv8<SLABS>(q, (int64_t)seq_c * fa.qkv_tok_stride + (h * Gv + hd) * 128 + sub * 8, fa);
         qh = norm_rope_head_regs(qh, fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
       } else {
-        qh = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)seq_c * hq + h * G + hd) * 128 + sub * 8);
+        qh = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)seq_c * hq + h * Gv + hd) * 128 + sub * 8);
       }
       if (!live) qh = u32x4_t{0u, 0u, 0u, 0u};
       *reinterpret_cast<u32x4_t*>(k_lds + r * 256 + sub * 16) = qh;
@@ -1284,9 +1300,9 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
 #pragma unroll
       for (int r = 0; r < 4; ++r) oacc[db][r] = oacc[db][r] * fa_ + other[(db * 4 + r) * 64 + lane] * fb_;
   }
-  const int seq = b0 + col / G, hd = col % G;
-  if (seq < batch && ctx[seq] > 0 && member[seq] != 0) {
-    const int64_t pidx = ((int64_t)seq * hq + h * G + hd) * slots + (slots - 1);
+  const int seq = b0 + col / Gv, hd = col % Gv;
+  if (col < P * Gv && seq < batch && ctx[seq] > 0 && member[seq] != 0) {
+    const int64_t pidx = ((int64_t)seq * hq + h * Gv + hd) * slots + (slots - 1);
     float* dst = part_o + pidx * 128 + 4 * quad;
 #pragma unroll
     for (int db = 0; db < 8; ++db) *reinterpret_cast<f32x4_t*>(dst + 16 * db) = oacc[db];
@@ -1414,28 +1430,31 @@ bool plan_shadow_prefix(const void* plan);      // was `plan` built with a share
 template <bool FUSED, bool KV8, int G, bool SLABS>
 int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                           void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
-                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, bool prefix);
+                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, bool prefix,
+                          int g_rt);
 
 // qkv as fp32 split-K slabs (fa.qkv_splits > 0) is an instantiation of its own: the bf16 form keeps its registers
 template <bool FUSED, bool KV8, int G = 8>
 int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                         void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
-                        void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse) {
+                        void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, int g_rt = 0) {
   const bool prefix = plan != nullptr && plan_shadow_prefix(plan);       // the plan was built with a shared prefix
   if constexpr (FUSED) {
     if (fa.qkv_splits > 0)
       return launch_decode_mfma8_s<FUSED, KV8, G, true>(q, kc, vc, bt, bt_stride, ctx, out, batch, hkv, block_size, max_context,
-                                                        scale, workspace, s, fa, plan, lse, prefix);
+                                                        scale, workspace, s, fa, plan, lse, prefix, g_rt);
   }
   return launch_decode_mfma8_s<FUSED, KV8, G, false>(q, kc, vc, bt, bt_stride, ctx, out, batch, hkv, block_size, max_context,
-                                                     scale, workspace, s, fa, plan, lse, prefix);
+                                                     scale, workspace, s, fa, plan, lse, prefix, g_rt);
 }
 
 template <bool FUSED, bool KV8, int G, bool SLABS>
 int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                           void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
-                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, bool prefix) {
-  const int hq = hkv * G;
+                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, bool prefix,
+                          int g_rt) {
+  const int Gv = G > 0 ? G : g_rt;
+  const int hq = hkv * Gv;
   const int slots = stream_slots(max_context);
   float* part_o = (float*)workspace;
   float* part_ml = part_o + (size_t)batch * hq * slots * 128;
@@ -1447,7 +1466,15 @@ int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, 
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_kernel<FUSED, KV8, G, SLABS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
-      nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the G = 8 kernel");
+      nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the matrix-core kernel");
+      return NVL_ELAUNCH;
+    }
+    // ... and for the shared-prefix pass of the same instantiation (69,632 B, above the 64 KiB default): made HERE, with the
+    // plain kernel's — the first launch of an instantiation is an eager warm-up, while the first launch WITH the pass may
+    // sit inside a stream capture (the engine captures a bucket's prefix graph when a step first wants it)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_prefix_kernel<FUSED, KV8, G, SLABS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kWaves * kMWaveLds) != hipSuccess) {
+      nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the shared-prefix kernel");
       return NVL_ELAUNCH;
     }
     attr_set = true;
@@ -1457,25 +1484,15 @@ int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, 
   if (prefix) {
     // shared-prefix pass first (its partial is in place when the merge runs; it reads q / K / V only, so its order
     // relative to the stream-K kernel — which appends the new token's K / V behind the prefix — does not matter)
-    static bool pattr_done[NVL_MAX_DEVICES] = {};
-    bool& pattr_set = pattr_done[nvl_device_slot()];
-    if (!pattr_set) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_prefix_kernel<FUSED, KV8, G, SLABS>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kWaves * kMWaveLds) != hipSuccess) {
-        nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the shared-prefix kernel");
-        return NVL_ELAUNCH;
-      }
-      pattr_set = true;
-    }
-    constexpr int P = 16 / G;
+    const int P = 16 / Gv;
     const int64_t pgrid = ((batch + P - 1) / P) * hkv;
     hipLaunchKernelGGL((decode_prefix_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)pgrid), dim3(256), kWaves * kMWaveLds, s,
                        (const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, (int)batch,
-                       hkv, block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan);
+                       hkv, block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt);
   }
   hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
                      (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
-                     block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan);
+                     block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
                      meta, ctx, (bf16_t*)out, hq, hkv, slots, lse, (const PlanHeader*)plan, prefix ? slots - 1 : -1);
   return nvl_check_launch("nvl_paged_attn_decode");
@@ -1637,15 +1654,19 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
   NVL_REQUIRE(workspace_bytes >= need, "%s: workspace %zu B < required %zu B", who, workspace_bytes, need);
   hipStream_t s = (hipStream_t)stream;
   const FusedArgs none = {};
-  const bool mfma = (G == 8 && (kv_dtype == NVL_KV_FP8 || !use_valu_g8())) || ((G == 2 || G == 4) && use_mfma_small_g());
+  NVL_REQUIRE(G <= 16, "%s: group size Hq/Hkv=%d exceeds 16 (the heads of a kv group fill one 16-column matrix tile)", who, G);
+  // Which kernel: G = 1 packed-dot; G = 2 / 4 / 8 their own matrix-core instantiations; every other group size up to 16
+  // (Qwen3-14B: 40 / 8 = 5, also per rank at TP = 2 / 4 / 8) the runtime-G instantiation of the same kernel.
+  const bool generic = G > 1 && G != 2 && G != 4 && G != 8;
+  const bool mfma = generic || (G == 8 && (kv_dtype == NVL_KV_FP8 || !use_valu_g8())) || ((G == 2 || G == 4) && use_mfma_small_g());
   if (fa && fa->qkv_splits > 0 && !mfma) {
     // fp32 split-K slabs as the qkv input: only the matrix-core kernel's prologue sums them
-    nvl_set_error("%s: qkv_splits > 0 needs the matrix-core kernel (Hq/Hkv in {2, 4, 8}; got %d)", who, G);
+    nvl_set_error("%s: qkv_splits > 0 needs the matrix-core kernel (Hq/Hkv in 2 ... 16; got %d)", who, G);
     return NVL_EUNSUPPORTED;
   }
   if (plan != nullptr && plan_shadow_prefix(plan)) {
     // a plan with a shared prefix starts every sequence's stream-K share behind it: only the matrix-core kernel knows
-    NVL_REQUIRE(mfma, "%s: a plan with a shared prefix needs the matrix-core kernel (Hq/Hkv in {2, 4, 8}; got %d)", who, G);
+    NVL_REQUIRE(mfma, "%s: a plan with a shared prefix needs the matrix-core kernel (Hq/Hkv in 2 ... 16; got %d)", who, G);
     NVL_REQUIRE(block_size % 128 == 0, "%s: a shared prefix needs block_size %% 128 == 0 (got %d)", who, block_size);
   }
   if (kv_dtype == NVL_KV_FP8) {
@@ -1657,6 +1678,13 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
               : launch_decode_stream_fp8<GG, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,      \
                                                     workspace, s, none, plan, lse);
+    if (generic)
+      return fa ? launch_decode_mfma8<true, true, 0>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
+                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,
+                                                     workspace, s, *fa, plan, lse, G)
+                : launch_decode_mfma8<false, true, 0>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
+                                                      batch, num_kv_heads, block_size, max_context, softmax_scale,
+                                                      workspace, s, none, plan, lse, G);
     if (use_mfma_small_g() && (G == 2 || G == 4)) {
 #define NVL_MFMA8_G(GG)                                                                                               \
   if (G == GG)                                                                                                        \
@@ -1682,7 +1710,7 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
                                                      batch, num_kv_heads, block_size, max_context, softmax_scale,
                                                      workspace, s, none, plan, lse);
       default:
-        nvl_set_error("%s: unsupported group size Hq/Hkv=%d (supported 1,2,4,8)", who, G);
+        nvl_set_error("%s: unsupported group size Hq/Hkv=%d (supported 1 ... 16)", who, G);
         return NVL_EUNSUPPORTED;
     }
 #undef NVL_DECODE8_CASE
@@ -1695,6 +1723,13 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
               : launch_decode_stream<GG, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,  \
                                                 batch, num_kv_heads, block_size, max_context, softmax_scale,      \
                                                 workspace, s, none, plan, lse);
+  if (generic)
+    return fa ? launch_decode_mfma8<true, false, 0>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
+                                                    batch, num_kv_heads, block_size, max_context, softmax_scale,
+                                                    workspace, s, *fa, plan, lse, G)
+              : launch_decode_mfma8<false, false, 0>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out,
+                                                     batch, num_kv_heads, block_size, max_context, softmax_scale,
+                                                     workspace, s, none, plan, lse, G);
   if (use_mfma_small_g() && (G == 2 || G == 4)) {
 #define NVL_MFMA_G(GG)                                                                                                \
   if (G == GG)                                                                                                        \
@@ -1725,7 +1760,7 @@ int decode_common(const void* q, void* k_cache, void* v_cache, const int32_t* bl
                 : launch_decode_stream<8, false>(q, k_cache, v_cache, block_tables, bt_stride, context_lens, out, batch,
                                                  num_kv_heads, block_size, max_context, softmax_scale, workspace, s, none, plan, lse);
     default:
-      nvl_set_error("%s: unsupported group size Hq/Hkv=%d (supported 1,2,4,8)", who, G);
+      nvl_set_error("%s: unsupported group size Hq/Hkv=%d (supported 1 ... 16)", who, G);
       return NVL_EUNSUPPORTED;
   }
 #undef NVL_DECODE_CASE
@@ -1793,8 +1828,8 @@ extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int n
     const int G = num_kv_heads > 0 ? num_q_heads / num_kv_heads : 0;
     NVL_REQUIRE((uintptr_t)shared_prefix_blocks % 4 == 0, "%s: shared_prefix must be 4-byte aligned", who);
     NVL_REQUIRE(block_size > 0 && block_size % 128 == 0, "%s: a shared prefix needs block_size %% 128 == 0 (got %d)", who, block_size);
-    NVL_REQUIRE((G == 8 && !use_valu_g8()) || ((G == 2 || G == 4) && use_mfma_small_g()),
-                "%s: a shared prefix needs the matrix-core decode kernel (Hq/Hkv in {2, 4, 8}; got %d)", who, G);
+    NVL_REQUIRE((G == 8 && !use_valu_g8()) || ((G == 2 || G == 4) && use_mfma_small_g()) || (G > 1 && G <= 16 && G != 2 && G != 4 && G != 8),
+                "%s: a shared prefix needs the matrix-core decode kernel (Hq/Hkv in 2 ... 16; got %d)", who, G);
   }
   NVL_REQUIRE((uintptr_t)plan % 16 == 0, "%s: plan must be 16-byte aligned", who);
   NVL_REQUIRE(batch >= 0 && batch <= 32768, "%s: batch=%lld out of range [0, 32768]", who, (long long)batch);

@@ -254,6 +254,17 @@ __global__ __launch_bounds__(256) void allgather_small_kernel(CommDev c, const u
   if (tid == 0) st_sys(&mine->epoch[b], epoch);
 }
 
+// *out = OR over the W ranks of the latched spin-timeout word (every rank's flag region is mapped here, uncached): the
+// serving path's view of nvl_allreduce_status — enqueue-only, so it can sit at the end of a captured decode step and travel
+// to the host with the step's sampled ids. A timeout on ANY rank invalidates the step on every rank (the late rank's
+// contribution was missing from the sums its peers used).
+__global__ __launch_bounds__(64) void allreduce_status_kernel(CommDev c, uint32_t* __restrict__ out) {
+  uint32_t e = 0;
+  if ((int)threadIdx.x < c.world) e = ld_sys(&reinterpret_cast<const Flags*>(c.base[threadIdx.x])->error);
+  const unsigned long long any = __ballot(e != 0);
+  if (threadIdx.x == 0) *out = any ? 1u : 0u;
+}
+
 Comm* as_comm(void* h) { return reinterpret_cast<Comm*>(h); }
 
 int check_rows(const Comm* cm, int64_t rows, int hidden, const char* who) {
@@ -417,6 +428,14 @@ extern "C" int nvl_allreduce_status(void* comm) {
     return NVL_ELAUNCH;
   }
   return NVL_OK;
+}
+
+extern "C" int nvl_allreduce_status_async(void* comm, void* status_out, void* stream) {
+  Comm* cm = as_comm(comm);
+  NVL_REQUIRE(cm && cm->connected, "nvl_allreduce_status_async: communicator not connected");
+  NVL_REQUIRE(status_out && (uintptr_t)status_out % 4 == 0, "nvl_allreduce_status_async: status_out must be a 4-byte aligned device pointer");
+  hipLaunchKernelGGL(allreduce_status_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cm->dev, (uint32_t*)status_out);
+  return nvl_check_launch("nvl_allreduce_status_async");
 }
 
 extern "C" int nvl_allreduce_destroy(void* comm) {

@@ -127,7 +127,13 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
   };
   // (measurement switches, NVL_WIDE_DBG: bit 0 = the loader stages step 0 only, bit 1 = every weight load re-reads step 0's
   //  lines — each stream alone inside the real pipeline; results are garbage)
+  //  — compiled in only by a probe build (NVL_PROBES=1 python -m nano_vllm_amd.build): the shipped library has no such switch
+#ifdef NVL_PROBES
   const bool dbg_no_x = dbg & 1, dbg_no_w = dbg & 2;
+#else
+  constexpr bool dbg_no_x = false, dbg_no_w = false;
+  (void)dbg;
+#endif
 
   if (wave >= NW) {
     // ---- loader wave(s): x tile of step s + 2 -> LDS stage (s + 2) % 3 while the consumers work on step s --------
@@ -518,7 +524,7 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
       // once, where two groups stream it twice) only in the decompositions whose register file holds 16 row tiles of
       // accumulators next to the weight ring — 4 waves with one SIMD each (NW = 3), or one column tile per wave.
       // More rows = more row groups, whose workgroups are paired on one XCD (see the kernel).
-      const bool big_ok = (nw == 3 || nt == 1) && env_int("NVL_WIDE_BIG_MT", 1) != 0;
+      const bool big_ok = nw == 3 || nt == 1;
       for (int mt_max : {16, 9}) {
         if (mt_max > 9 && (!big_ok || mtiles <= 9)) continue;
         WidePlan p;
@@ -549,10 +555,12 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
     best->bk = 64;
     best->steps *= 2;
   }
+#ifdef NVL_PROBES
   if (best_t < 1e30 && env_int("NVL_WIDE_DEBUG", 0))
     fprintf(stderr, "nvl_linear_wide plan m=%lld n=%d k=%d mode=%d: nt=%d nw=%d mt=%d groups=%d tiles=%d split=%d steps=%d x %d -> %d wgs, model %.1f us\n",
             (long long)m, n, k, mode, best->nt, best->nw, best->mt, best->mgroups, best->tiles, best->split, best->steps, best->bk,
             best->tiles * best->split * best->mgroups, best_t);
+#endif
   return best_t < 1e30;
 }
 
@@ -572,7 +580,11 @@ int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, in
   }
   // two row groups: pair them on one XCD (see the kernel); NVL_WIDE_PAIR=0 keeps the plain (tile, split, group) grid
   static const bool pair_ok = env_int("NVL_WIDE_PAIR", 1) != 0;
+#ifdef NVL_PROBES
   static const int dbg = env_int("NVL_WIDE_DBG", 0);
+#else
+  constexpr int dbg = 0;
+#endif
   if (p.mgroups == 2 && pair_ok) {
     const unsigned gx = (unsigned)((p.tiles + 7) / 8) * 16;
     hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK>), dim3(gx, p.split, 1),

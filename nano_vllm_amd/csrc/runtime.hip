@@ -22,7 +22,7 @@ int nvl_check_launch(const char* what) {
   return NVL_OK;
 }
 
-extern "C" int nvl_abi_version(void) { return 5; }   // 5: nvl_decode_plan takes the shared-prefix block count (shared-prefix attention pass); 4: fused lm_head sampler retired; qkv split-K slabs into the fused decode attention (3: per-step decode plan, LSE outputs)
+extern "C" int nvl_abi_version(void) { return 6; }   // 6: nvl_allreduce_status_async (a latched collective timeout travels with the step's ids), decode attention for every group size 1 ... 16; 5: nvl_decode_plan takes the shared-prefix block count (shared-prefix attention pass); 4: fused lm_head sampler retired; qkv split-K slabs into the fused decode attention (3: per-step decode plan, LSE outputs)
 
 extern "C" const char* nvl_last_error(void) { return g_err; }
 

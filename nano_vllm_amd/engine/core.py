@@ -24,8 +24,10 @@ def _worker_main(config, rank, env):
         # runtime starts in this fresh process). Ranks whose spinning collective kernels share CUs starve each other on a
         # time-shared GPU (profiles/r05_tp2_cu_mask_experiment.json: 0 of 16 runs stall with disjoint slices, 4 of 6
         # without); rank 0's runtime is already up and keeps the whole chip.
-        per = 256 // config.tensor_parallel_size
-        os.environ["HSA_CU_MASK"] = f"0:{rank * per}-{(rank + 1) * per - 1}"
+        # (the CU count comes from the parent, which has a runtime up: NVL_TP_CU_COUNT in `env`; MI355X has 256)
+        per = int(os.environ.get("NVL_TP_CU_COUNT", "256")) // config.tensor_parallel_size
+        if per >= 1:
+            os.environ["HSA_CU_MASK"] = f"0:{rank * per}-{(rank + 1) * per - 1}"
     from .runner import ModelRunner
     ModelRunner(config, rank)              # never returns until "exit" (runner.loop)
 
@@ -50,6 +52,9 @@ class LLMEngine:
             import torch.multiprocessing as mp
             ctx = mp.get_context("spawn")
             env = {k: v for k, v in os.environ.items() if k.startswith("NVL_")}
+            if env.get("NVL_TP_SHARE_GPU") == "1":
+                import torch
+                env["NVL_TP_CU_COUNT"] = str(torch.cuda.get_device_properties(0).multi_processor_count)
             for rank in range(1, config.tensor_parallel_size):
                 proc = ctx.Process(target=_worker_main, args=(config, rank, env))
                 proc.start()

@@ -474,6 +474,12 @@ class ModelRunner:
         self.graphs_px: dict[int, torch.cuda.CUDAGraph] = {}
         self.prefix_steps = 0                # decode steps that ran the shared-prefix pass (reporting)
         self._step_done = [torch.cuda.Event(), torch.cuda.Event()]
+        # TP with the xGMI P2P collectives: every spin of those kernels is bounded, and a timeout is LATCHED in the shared
+        # flag region while the step carries on with an invalid sum. The last node of every step (prefill and decode,
+        # eager and captured) ORs the ranks' latches into `comm_status_dev`; rank 0 takes the word to the host with the
+        # step's ids and raises from step() / generate() (exit() keeps its own check as the backstop).
+        self.comm_status_dev = torch.zeros(1, dtype=torch.int32, device=self.device)
+        self.comm_status_host = torch.zeros(2, dtype=torch.int32, device="cpu", pin_memory=True)
 
     # ------------------------------------------------------------------ warm-up + KV cache
     def warmup_model(self):
@@ -633,7 +639,10 @@ class ModelRunner:
         pack = 16 // (self.geo["heads"] // self.geo["kv_heads"])
         esize = 1 if self.config.kv_cache_dtype == "fp8" else 2
         m = int(member.sum())
-        saved = k * self.block_size * (m - -(-m // pack)) * self.geo["kv_heads"] * 2 * 128 * esize
+        # the pass reads the prefix once per pack of CONSECUTIVE rows that holds a member (non-members ride along as zero
+        # columns): members scattered among non-members share less than m / pack packs
+        npacks = len(np.unique(np.nonzero(member)[0] // pack))
+        saved = k * self.block_size * (m - npacks) * self.geo["kv_heads"] * 2 * 128 * esize
         return (k, member) if saved >= self.share_prefix_min_bytes else (0, None)
 
     # ------------------------------------------------------------------ forward
@@ -668,6 +677,19 @@ class ModelRunner:
         hidden = self.model(t["ids"][r0:r1], t["pos"][r0:r1])
         self._sample(hidden, t["temps"][r0:r1], self.tokens_dev[r0:r1], t["rng"][:1], sampler, t["rkey"][r0:r1])
         reset_context()
+        self._collect_comm_status()
+
+    def _collect_comm_status(self) -> None:
+        """Last node of a step (every rank; captured with the decode graphs): did any rank's P2P collective time out?"""
+        if self.p2p:
+            from .. import tp
+            tp.comm().status_async(self.comm_status_dev)
+
+    def _raise_if_collective_timed_out(self, word: int, what: str) -> None:
+        if word:
+            raise ops.NvlError(f"a tensor-parallel P2P collective gave up waiting for a peer during {what}: the step's sums, and "
+                               "every token sampled from them, are invalid (nvl_allreduce_status). NVL_TP_P2P=0 runs the "
+                               "collectives over the process group instead")
 
     @torch.inference_mode()
     def _forward_decode(self, bs: int, prefix: bool = False):
@@ -689,9 +711,12 @@ class ModelRunner:
         bucket = next((b for b in self.graph_bs if b >= n), None) if self.graphs else None
         prefix = self.share_prefix and int(self.dstage.np["shp"][0]) > 0       # (every rank reads the same image)
         self.prefix_steps += int(prefix)
+        if bucket is not None and prefix and bucket not in self.graphs_px and not self._capture_prefix_graph(bucket):
+            # the capture failed (single rank only; _capture_prefix_graph raises under TP): this step replays the bucket's
+            # plain graph, whose plan is built without the staged group
+            prefix = False
+            self.prefix_steps -= 1
         if bucket is not None and prefix:
-            if bucket not in self.graphs_px:
-                self._capture_prefix_graph(bucket)
             self.graphs_px[bucket].replay()
         elif bucket is not None:
             self.graphs[bucket].replay()
@@ -701,8 +726,10 @@ class ModelRunner:
         done = self._step_done[self._flight_parity]
         if self.rank == 0:
             host[:n].copy_(self.tokens_dev[:n], non_blocking=True)
+            if self.p2p:
+                self.comm_status_host[self._flight_parity:self._flight_parity + 1].copy_(self.comm_status_dev, non_blocking=True)
         done.record()
-        self._inflight.append((n, host, done))
+        self._inflight.append((n, host, done, self._flight_parity))
         self._flight_parity ^= 1
 
     def decode_begin(self, seqs: list[Sequence], staged: bool = False) -> int:
@@ -722,8 +749,10 @@ class ModelRunner:
 
     def decode_end(self) -> list[int] | None:
         """Wait for the OLDEST step enqueued by `decode_begin` and return its sampled ids."""
-        n, host, done = self._inflight.pop(0)
+        n, host, done, parity = self._inflight.pop(0)
         done.synchronize()
+        if self.p2p and self.rank == 0:
+            self._raise_if_collective_timed_out(int(self.comm_status_host[parity]), "a decode step")
         return host[:n].tolist()
 
     def stage_next_decode(self, seqs: list[Sequence]) -> None:
@@ -748,6 +777,7 @@ class ModelRunner:
         hidden = self.model(t["ids"][:n], t["pos"][:n])
         self._sample(hidden, t["temps"][:ns], self.tokens_dev[:ns], t["rng"][:1], self.sampler, t["rkey"][:ns])
         reset_context()
+        self._collect_comm_status()
 
     def _run_prefill(self, seqs: list[Sequence]) -> list[int] | None:
         info = self.prepare_prefill(seqs)
@@ -759,7 +789,11 @@ class ModelRunner:
         self._launch_prefill(info)
         ns = info["ns"]
         self.tokens_host[:ns].copy_(self.tokens_dev[:ns], non_blocking=True)
+        if self.p2p:
+            self.comm_status_host[:1].copy_(self.comm_status_dev, non_blocking=True)
         torch.cuda.current_stream().synchronize()
+        if self.p2p:
+            self._raise_if_collective_timed_out(int(self.comm_status_host[0]), "a prefill step")
         return self.tokens_host[:ns].tolist()
 
     def run(self, seqs: list[Sequence], is_prefill: bool) -> list[int] | None:
@@ -784,23 +818,40 @@ class ModelRunner:
             if pool is None:
                 pool = graph.pool()
             self.graphs[bs] = graph
+        self.graph_pool = pool
         if self.share_prefix:
-            # one eager step WITH the shared-prefix pass on the neutral inputs (every row is padding: the pass finds
-            # nothing to do): its kernel's LDS reservation is made here, outside any capture
-            self._forward_decode(self.graph_bs[0], prefix=True)
+            # The graph of the LARGEST bucket with the shared-prefix pass is captured here, warm, on the neutral inputs (every
+            # row is padding: the pass finds nothing to do) — a failure of that path surfaces at start-up, and the pool holds
+            # what a prefix graph needs before the serving path asks for one; the other buckets' prefix graphs are captured
+            # when a step first wants them (most workloads never do). The kernels' LDS reservations are made by the launcher
+            # of the plain kernel (attn_decode.hip), i.e. during the eager warm-ups above, never inside a capture.
+            self._forward_decode(self.graph_bs[-1], prefix=True)
+            torch.cuda.synchronize()
+            self._capture_prefix_graph(self.graph_bs[-1])
         torch.cuda.synchronize()
         from .. import layers
         layers.release_tuning_scratch()                 # the decode-GEMM choices of every bucket are made by now
-        self.graph_pool = pool
 
     @torch.inference_mode()
-    def _capture_prefix_graph(self, bs: int) -> None:
+    def _capture_prefix_graph(self, bs: int) -> bool:
         """The decode graph of bucket `bs` WITH the shared-prefix attention pass, captured the first time a step wants
-        it (most workloads never do). No warm-up run: the static buffers hold a real step's inputs by now, and every
-        choice the launches make was made when the bucket's plain graph was captured. Every rank captures at the same
-        step (the decision is read from the staged image)."""
+        it (most workloads never do; the largest bucket's is captured at start-up). No warm-up run on the serving path:
+        the static buffers hold a real step's inputs by now, every choice the launches make was made when the bucket's
+        plain graph was captured, and the allocations come out of the plain graphs' pool. Every rank captures at the same
+        step (the decision is read from the staged image). Returns False when the capture failed on a single-rank
+        engine (the caller runs the step plain, and the pass stays off for this bucket); under TP a failure is raised —
+        the ranks could not agree on a fallback without another exchange."""
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph, self.graph_pool):
-            self._forward_decode(bs, prefix=True)
+        try:
+            with torch.cuda.graph(graph, self.graph_pool):
+                self._forward_decode(bs, prefix=True)
+        except Exception as e:      # OOM of the pool's headroom, a launch refused inside the capture
+            if self.world_size > 1:
+                raise
+            import warnings
+            warnings.warn(f"shared-prefix graph of bucket {bs} could not be captured ({e!r}); the pass is off")
+            self.share_prefix = False
+            return False
         self.graphs_px[bs] = graph
+        return True

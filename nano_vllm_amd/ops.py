@@ -17,7 +17,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libnvl_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # name -> (restype, argtypes); mirrors include/nvl.h one to one (checked by tests/test_abi.py)
 SIGNATURES = {
@@ -71,6 +71,7 @@ SIGNATURES = {
                                           c_void_p]),
     "nvl_allreduce_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "nvl_allreduce_status": (c_int, [c_void_p]),
+    "nvl_allreduce_status_async": (c_int, [c_void_p, c_void_p, c_void_p]),
     "nvl_allreduce_destroy": (c_int, [c_void_p]),
     "nvl_sample_exponentials_host": (None, [c_uint64, c_uint64, c_int64, c_int64, c_int64, c_void_p]),
 }
@@ -399,7 +400,7 @@ def paged_attn_decode_fused(qkv: torch.Tensor, q_norm_w, k_norm_w, eps: float, c
     """Decode step in one launch: q/k-norm + RoPE (position = context_len - 1) + KV-cache store of the
     new token + paged attention. qkv: raw qkv GEMM output [B, (Hq + 2*Hkv)*128] bf16 — or, for a deep-K projection,
     the fp32 split-K slabs [S, B, (Hq + 2*Hkv)*128] of `linear_wide(..., LINEAR_PARTIAL)` (S <= 8; summed and rounded
-    in the attention prologue: no separate slab-reduce launch; matrix-core kernel only, Hq / Hkv in {2, 4, 8})."""
+    in the attention prologue: no separate slab-reduce launch; matrix-core kernel only, Hq / Hkv in 2 ... 16)."""
     _dev(qkv, "qkv")
     splits, split_stride = 0, 0
     if qkv.dtype == torch.float32:
@@ -425,11 +426,14 @@ def paged_attn_decode_fused(qkv: torch.Tensor, q_norm_w, k_norm_w, eps: float, c
 
 def decode_attention_takes_qkv_slabs(num_q_heads: int, num_kv_heads: int) -> bool:
     """Can `paged_attn_decode_fused` sum fp32 qkv slabs itself for this head geometry? (the matrix-core kernel: group
-    sizes 2, 4, 8 unless the packed-dot forms are forced by NVL_DECODE_MFMA=0 / NVL_DECODE_G8_VALU=1)"""
+    sizes 2 ... 16 — 2, 4, 8 unless their packed-dot forms are forced by NVL_DECODE_MFMA=0 / NVL_DECODE_G8_VALU=1; every other
+    group size, e.g. Qwen3-14B's 40 / 8 = 5, only has the matrix-core kernel)"""
     g = num_q_heads // max(num_kv_heads, 1)
     if g == 8:
         return os.environ.get("NVL_DECODE_G8_VALU", "0") != "1"
-    return g in (2, 4) and os.environ.get("NVL_DECODE_MFMA", "1") != "0"
+    if g in (2, 4):
+        return os.environ.get("NVL_DECODE_MFMA", "1") != "0"
+    return 1 < g <= 16
 
 
 def attn_prefill_varlen(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens_q: torch.Tensor,
@@ -612,6 +616,13 @@ class P2PComm:
 
     def status(self) -> None:
         _check(lib().nvl_allreduce_status(self._h))
+
+    def status_async(self, out: torch.Tensor) -> None:
+        """out[0] (int32, device) <- 1 if any rank of the group has latched a spin timeout so far, else 0. Enqueue-only
+        (capturable): the serving path's form of `status`."""
+        _dev(out, "out")
+        assert out.dtype == torch.int32 and out.numel() >= 1
+        _check(lib().nvl_allreduce_status_async(self._h, out.data_ptr(), _stream()))
 
     def close(self) -> None:
         if self._h is not None:

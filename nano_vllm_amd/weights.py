@@ -34,8 +34,10 @@ QWEN3_SHAPES = {
     "qwen3-tiny-untied": (256, 512, 3, 8, 2, False),     # G = 4, separate lm_head (8B-like)
     "qwen3-tiny-g8": (512, 768, 2, 8, 1, False),          # G = 8, one kv head (32B / TP=8 per-rank shape)
     "qwen3-tiny-kv8": (512, 1024, 2, 16, 8, False),       # 8 kv heads: shards down to 1 kv head per rank at TP = 8
+    "qwen3-tiny-g5": (512, 768, 2, 10, 2, False),         # G = 5 (Qwen3-14B's 40 / 8): a group size that does not divide 16
     # two full-width layers of the large models (tests: the layer code paths real 8B / 32B widths take)
     "qwen3-8b-2l": (4096, 12288, 2, 32, 8, False),
+    "qwen3-14b-2l": (5120, 17408, 2, 40, 8, False),
     "qwen3-32b-2l": (5120, 25600, 2, 64, 8, False),
     # what ONE rank of Qwen3-32B at tensor_parallel_size = 8 holds (models/qwen3.py:29-38, layers/linear.py:54-156: 8 query
     # heads, 1 kv head, intermediate 25600 / 8; with vocab_size 151936 / 8 also its embedding / lm_head shard): run as a

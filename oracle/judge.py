@@ -120,7 +120,7 @@ class Judge:
 
 def judge_run(cfg: dict, weights: dict, prompts, max_tokens, rec: list[dict], num_blocks: int, device=None,
               temperatures=None, seed: int = 0, floor_rel: float | None = None, on_step=None, ordinal_base: int = 0,
-              **sched_kw) -> Verdict:
+              block_size: int = 256, **sched_kw) -> Verdict:
     """Judge a recorded product run. `rec`: per engine step {"prefill": bool, "seq_ids": [...], "tables": [[...]],
     "tokens": [...], optional "logits": the product's logits}. Two oracle engines (compiled and eager rounding) are
     teacher-forced with the product's tokens; scheduling (phase, batch composition, block tables) must be identical
@@ -134,7 +134,8 @@ def judge_run(cfg: dict, weights: dict, prompts, max_tokens, rec: list[dict], nu
 
     from .engine import OracleEngine
     from .model import OracleQwen3
-    engines = [OracleEngine(OracleQwen3(cfg, weights, compiled=c, device=device), num_blocks, 256, **sched_kw)
+    # (block_size: Config.kvcache_block_size, config.py:22 — any multiple of 256)
+    engines = [OracleEngine(OracleQwen3(cfg, weights, compiled=c, device=device), num_blocks, block_size, **sched_kw)
                for c in ((True, False) if floor_rel is None else (True,))]
     temps = list(temperatures) if temperatures is not None else [0.0] * len(prompts)
     for eng in engines:

@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for sym in _declared():
         assert hasattr(lib, sym), f"{sym} declared in include/nvl.h but not exported"
     lib.nvl_abi_version.restype = ctypes.c_int
-    assert lib.nvl_abi_version() == 5
+    assert lib.nvl_abi_version() == 6
 
 
 def test_ctypes_binding_matches_header():
@@ -47,9 +47,11 @@ def test_host_side_argument_validation_without_gpu():
     assert rc == -1 and b"not a multiple" in lib.nvl_last_error()
     rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8, 4096, 0.1, 16, 1 << 30, 7, None, None, None)
     assert rc == -1 and b"kv_dtype" in lib.nvl_last_error()
-    # group sizes outside 1, 2, 4, 8 are refused (either cache dtype), not emulated
-    rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 48, 16, 256, 16, 4096, 0.1, 16, 1 << 30, 1, None, None, None)
-    assert rc == -3 and b"group size" in lib.nvl_last_error()
+    # every group size Hq / Hkv from 1 to 16 has a kernel (round 6: Qwen3-14B is 40 / 8 = 5); beyond 16 the heads of a kv
+    # group do not fit the kernel's one 16-column matrix tile: refused (either cache dtype), not emulated
+    for kv_dtype in (0, 1):
+        rc = lib.nvl_paged_attn_decode(16, 16, 16, 16, 16, 16, 16, 4, 34, 2, 256, 16, 4096, 0.1, 16, 1 << 30, kv_dtype, None, None, None)
+        assert rc == -1 and b"group size" in lib.nvl_last_error()
     # fused decode entry: rope table is mandatory; q/k norm weights come as a pair
     rc = lib.nvl_paged_attn_decode_fused(16, 4096, None, None, 1e-6, None, 0, 16, 16, 16, 16, 16, 16, 4, 16, 8, 256, 8,
                                          4096, 0.1, 16, 1 << 30, 0, None, None, 0, 0, None)

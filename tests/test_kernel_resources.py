@@ -28,10 +28,10 @@ def kernels():
 def test_no_kernel_spills_or_uses_scratch(kernels):
     """No kernel touches scratch memory or spills vector registers; no kernel spills scalar registers either, with ONE
     family excepted: the fused decode attention reading its qkv input as fp32 split-K slabs (decode_mfma8_kernel<true, *,
-    *, SLABS = true>, round 5) sits at the 102-SGPR limit and parks <= 24 scalars in lanes of a vector register
+    *, SLABS = true>, round 5; G = 0 is the runtime-group-size instantiation of round 6) sits at the 102-SGPR limit and parks <= 24 scalars in lanes of a vector register
     (v_writelane / v_readlane in the segment prologue, never memory) — the bf16-input instantiations stay clean."""
     def slabs(name):
-        return re.search(r"decode_mfma8_kernelILb1ELb[01]ELi[248]ELb1EE", name) is not None
+        return re.search(r"decode_mfma8_kernelILb1ELb[01]ELi[0248]ELb1EE", name) is not None
     bad = [(r["name"], r.get("private_segment_fixed_size"), r.get("vgpr_spill_count"), r.get("sgpr_spill_count"))
            for r in kernels
            if r.get("private_segment_fixed_size", 0) or r.get("vgpr_spill_count", 0)

@@ -364,7 +364,7 @@ def _paged_setup(lens, hkv, bs, seed, extra_blocks=3):
     return kc, vc, bt
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (40, 8), (20, 4), (5, 1), (24, 8)])
 @pytest.mark.parametrize("lens", [[1], [255, 256, 257], [1, 100, 1023, 1024, 1025, 2048, 17], [4096, 3, 0, 700]])
 def test_paged_attn_decode(ops, hq, hkv, lens):
     bs = 256
@@ -387,7 +387,7 @@ def test_paged_attn_decode(ops, hq, hkv, lens):
             assert torch.count_nonzero(o[i]) == 0  # padded rows produce zeros
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (16, 2)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (16, 2), (40, 8), (20, 4), (5, 1), (24, 8)])
 @pytest.mark.parametrize("lens", [[1], [255, 256, 257], [1, 100, 1023, 1024, 1025, 2048, 17, 0, 0, 640], [4096, 3, 0, 700],
                                   [0, 0, 5, 0, 0, 0, 900, 0]])
 def test_paged_attn_decode_lse_checksum_and_per_step_plan(ops, hq, hkv, lens):
@@ -424,7 +424,7 @@ def test_paged_attn_decode_lse_checksum_and_per_step_plan(ops, hq, hkv, lens):
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (40, 8), (20, 4), (5, 1), (24, 8)])
 @pytest.mark.parametrize("lens", [[1], [255, 256, 257, 33], [1, 100, 1023, 1024, 1025, 2048, 17, 0, 640], [4096, 3, 0, 700]])
 @pytest.mark.parametrize("with_norm", [True, False])
 def test_paged_attn_decode_fused_equals_unfused(ops, hq, hkv, lens, with_norm):
@@ -501,7 +501,7 @@ def test_paged_attn_decode_fused_equals_unfused(ops, hq, hkv, lens, with_norm):
         assert float((lse.cpu()[live] - lse_ref[live]).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (16, 2)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (16, 2), (40, 8), (20, 4), (5, 1), (24, 8)])
 @pytest.mark.parametrize("splits", [1, 2, 5, 8])
 @pytest.mark.parametrize("kv", ["bf16", "fp8"])
 def test_paged_attn_decode_fused_sums_qkv_split_k_slabs(ops, hq, hkv, splits, kv):
@@ -567,7 +567,7 @@ def test_paged_attn_decode_fused_refuses_slabs_for_the_packed_dot_kernel(ops):
                                     torch.ones(1, dtype=torch.int32, device="cuda"), 8, 0.1, 256, ws)
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (16, 2), (8, 1), (32, 8)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (16, 2), (8, 1), (32, 8), (40, 8), (20, 4), (5, 1), (24, 8)])
 def test_paged_attn_decode_large_batch(ops, hq, hkv):
     """bench-like shape: batch 256, contexts 100..2048; group size 2 (Qwen3-0.6B), 8 with two / one kv heads
     (Qwen3-32B per-rank shapes at TP = 4 / 8: the matrix-core decode kernel), 4 (Qwen3-8B)."""
@@ -598,7 +598,7 @@ def _cu(lens):
     return torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (8, 1), (32, 8), (16, 2)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (8, 1), (32, 8), (16, 2), (40, 8), (20, 4), (5, 1), (24, 8)])
 @pytest.mark.parametrize("lens", [[1], [128], [129, 64, 300], [5, 1000, 33, 257]])
 def test_prefill_contiguous(ops, hq, hkv, lens):
     n = sum(lens)
@@ -662,7 +662,7 @@ def test_prefill_tile_list_in_registers_and_in_lds(ops, nseq):
     assert float((lse.cpu() - lse_ref).abs().max()) <= 2e-3
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1), (32, 8)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 1), (32, 8), (40, 8), (20, 4), (5, 1), (24, 8)])
 @pytest.mark.parametrize("lq_lk", [[(1, 257)], [(100, 356), (256, 256), (7, 1031)], [(300, 812), (64, 64)]])
 def test_prefill_paged_prefix(ops, hq, hkv, lq_lk):
     """Prefix-cache / chunked-prefill path: Lq < Lk, K/V from the paged cache, mask bottom-right."""
@@ -738,7 +738,7 @@ def test_prefill_long_sequence_vs_chunked_oracle(ops, hq, hkv, n):
     assert err_t <= 2e-2 * o_ref[tail].float().abs().max().item() + 1e-3, err_t
 
 
-@pytest.mark.parametrize("hq,hkv", [(8, 1), (16, 8)])
+@pytest.mark.parametrize("hq,hkv", [(8, 1), (16, 8), (40, 8), (20, 4), (5, 1), (24, 8)])
 def test_prefill_paged_continuation_of_a_prompt_longer_than_the_token_budget(ops, hq, hkv):
     """scheduler.py:42-46 chunk rule at max_num_batched_tokens = 16384: a 20,000-token prompt is prefilled as
     16,384 tokens, then 3,616 tokens whose keys are ALL 20,000 tokens read from the paged cache through the
@@ -827,7 +827,7 @@ def test_fp8_kv_store_matches_torch_cast_bit_for_bit(ops, n, h, hkv):
     assert row.tolist() == [448.0, -448.0, 448.0, 448.0] and not torch.isnan(kc.cpu().float()).any()
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (16, 2), (64, 8)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (8, 8), (32, 8), (8, 1), (16, 2), (64, 8), (40, 8), (20, 4), (5, 1), (24, 8)])
 @pytest.mark.parametrize("lens", [[1], [255, 256, 257, 33], [1, 100, 1023, 1024, 1025, 2048, 17, 0, 640], [4096, 3, 0, 700]])
 def test_fp8_kv_decode_fused_vs_oracle_on_the_dequantised_cache(ops, hq, hkv, lens):
     """nvl_paged_attn_decode_fused with an fp8 cache: (1) the new token's K/V rows land in the cache as the fp8 cast
@@ -886,7 +886,7 @@ def test_fp8_kv_decode_fused_vs_oracle_on_the_dequantised_cache(ops, hq, hkv, le
     assert float(d2) <= 2e-2 * float(o_ref.float()[live].abs().max()) + 1e-3
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (40, 8), (20, 4), (5, 1), (24, 8)])
 def test_fp8_kv_prefill_paged_prefix(ops, hq, hkv):
     """Prefix-cache / chunk-continuation prefill reading an fp8 cache == the oracle on the dequantised cache."""
     bs = 256

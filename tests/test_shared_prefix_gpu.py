@@ -64,7 +64,7 @@ LENS = [513, 300, 0, 1024, 1025, 2048, 515, 0, 0, 640, 4096, 513, 900, 901, 0, 7
 PRIVATE = (1, 12, 13)
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (16, 2), (64, 8)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (16, 2), (64, 8), (40, 8), (20, 4), (5, 1), (24, 8)])
 @pytest.mark.parametrize("shared", [1, 2])
 @pytest.mark.parametrize("kv", ["bf16", "fp8"])
 def test_fused_decode_with_a_shared_prefix_pass(ops, hq, hkv, shared, kv):
@@ -125,7 +125,7 @@ def test_fused_decode_with_a_shared_prefix_pass(ops, hq, hkv, shared, kv):
     assert torch.equal(o2, o0) and torch.equal(lse2, lse0) and torch.equal(k2.view(torch.uint8), k0.view(torch.uint8))
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (40, 8), (20, 4), (5, 1), (24, 8)])
 @pytest.mark.parametrize("splits", [2, 5])
 def test_shared_prefix_pass_on_qkv_split_k_slabs(ops, hq, hkv, splits):
     """The deep-K models hand the fused decode attention their qkv projection as fp32 split-K slabs (Qwen3-8B in BASELINE
@@ -166,7 +166,7 @@ def test_shared_prefix_pass_on_qkv_split_k_slabs(ops, hq, hkv, splits):
     assert float((o_plain.float() - outs[1][0].float()).abs().max()) <= 1e-2 * float(o_plain.float().abs().max())
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (40, 8), (20, 4), (5, 1), (24, 8)])
 def test_unfused_decode_clamps_the_shared_prefix_to_the_shortest_row(ops, hq, hkv):
     """nvl_paged_attn_decode (K/V already stored) with two common blocks claimed while one member ends INSIDE the second
     one (500 tokens: its tail is the common block's content) and one is a single token: the device clamps the pass to

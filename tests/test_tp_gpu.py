@@ -389,3 +389,41 @@ def test_tp2_sampling_equals_tp1_draws(tiny_ckpt, monkeypatch):
     same_first = sum(a[0] == b[0] for a, b in zip(one, two))
     print(f"TP=2 vs TP=1 first sampled tokens equal: {same_first}/{len(prompts)}")
     assert same_first >= len(prompts) - 2
+
+
+@pytest.mark.timeout(900)
+def test_tp2_generate_raises_when_a_p2p_collective_has_latched_a_timeout(tiny_ckpt, monkeypatch):
+    """A P2P collective whose peer never arrives gives up after a bounded spin, LATCHES the fact in the rank's flag region
+    and carries on with an invalid sum (csrc/comm.hip `await`). The serving path must not hand the tokens sampled from
+    such a step to the caller: the last node of every step ORs the ranks' latches into one word that travels to the host
+    with the step's ids (nvl_allreduce_status_async), and step() / generate() raise. Injected here by writing the latch
+    word of rank 0's flag region (offset of Flags::error in the 64 KiB region ahead of the data buffer)."""
+    from nano_vllm_amd import LLM, SamplingParams, ops, tp
+    monkeypatch.setenv("NVL_TP_SHARE_GPU", "1")
+    monkeypatch.setenv("NVL_TP_BACKEND", "gloo")
+    monkeypatch.setenv("NVL_TP_PORT", str(_free_port()))
+    monkeypatch.setenv("NVL_TP_P2P", "1")
+    monkeypatch.setenv("NVL_TP_P2P_STRESS_EPOCHS", "100")
+    llm = LLM(tiny_ckpt, enforce_eager=False, max_model_len=2048, num_kvcache_blocks=32, max_num_seqs=16,
+              tensor_parallel_size=2)
+    try:
+        assert llm.model_runner.p2p, "the P2P collectives are not in use: nothing to latch"
+        sp = SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True)
+        prompts = [[1, 2, 3, 4, 5], list(range(40, 90))]
+        outs = llm.generate(prompts, sp, use_tqdm=False)
+        assert [len(o["token_ids"]) for o in outs] == [6, 6]            # a healthy group: nothing raised
+        flag_bytes, error_off = 64 * 1024, (2 * 256 * 8 + 256) * 4      # Flags{flag0, flag1, epoch, error} of comm.hip
+        ptr = int(ops.lib().nvl_allreduce_buffer(tp.comm()._h)) - flag_bytes + error_off
+
+        class _Word:
+            __cuda_array_interface__ = {"shape": (1,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+        word = torch.as_tensor(_Word(), device="cuda")
+        assert int(word.item()) == 0
+        word.fill_(1)
+        torch.cuda.synchronize()
+        with pytest.raises(ops.NvlError, match="gave up waiting for a peer"):
+            llm.generate(prompts, sp, use_tqdm=False)
+        word.fill_(0)                                                   # (so that exit()'s own check finds a clean group)
+        torch.cuda.synchronize()
+    finally:
+        llm.exit()
