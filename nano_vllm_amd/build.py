@@ -15,13 +15,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIBDIR = os.path.join(HERE, "lib")
+LIBDIR = os.environ.get("NVL_LIBDIR") or os.path.join(HERE, "lib")   # (NVL_LIBDIR: a probe build next to the shipped one)
 LIB = os.path.join(LIBDIR, "libnvl_hip.so")
 STAMP = os.path.join(LIBDIR, "libnvl_hip.stamp")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 if os.environ.get("NVL_PROBES") == "1":       # probe build: the kernels' measurement switches (NVL_WIDE_DBG / _DEBUG) exist
     FLAGS.append("-DNVL_PROBES")
+    subprocess.run([sys.executable, os.path.join(HERE, "..", "tools", "gen_wide_asm.py"), "--probes"], check=True)
 
 
 def _hipcc() -> str:
@@ -37,7 +38,7 @@ def sources() -> list[str]:
 
 def _digest() -> str:
     h = hashlib.sha256()
-    files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]
     files.append(os.path.join(HERE, "..", "include", "nvl.h"))
     for f in files:
         with open(f, "rb") as fh:
@@ -57,7 +58,7 @@ def is_fresh() -> bool:
 def _source_digest(src: str) -> str:
     """One translation unit: the source, every header it could include, the flags."""
     h = hashlib.sha256()
-    for f in [src] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]:
+    for f in [src] + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))]:
         with open(f, "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())

@@ -81,8 +81,24 @@ __host__ __device__ constexpr int wide_stages(int mt, int bk = 128) { return 3 *
 // file and cannot host another wave.
 __host__ __device__ constexpr int wide_loaders(int nw) { return nw == 4 ? 2 : 1; }
 
-template <int MT, int NT, int NW, int EPI, int RING, bool PACKED, int BK = 128>
-__global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
+// The hand-scheduled consumer K loop (inline asm, generated: tools/gen_wide_asm.py describes the schedule) for the
+// one-wave-per-SIMD shape NT = 2, NW = 3, 64-column k steps, tile-packed weights, 12 or 16 row tiles.
+#include "gemm_wide_core.inc"
+#ifdef NVL_PROBES
+#include "gemm_wide_core_probes.inc"       // (generated by the probe build: the loop without its reads / without its MFMAs)
+#endif
+__host__ __device__ constexpr bool wide_core_shape(int mt, int nt, int nw, int bk, bool packed) {
+  return (mt == 16 || mt == 12) && nt == 2 && nw == 3 && bk == 64 && packed;
+}
+// Loader waves of a workgroup. The core's consumers stay within 256 registers, so a FIFTH wave fits a SIMD next to one of
+// them: two loaders, each staging every other 1-KiB piece of the x tile — one wave's 63 loads in flight (the 6-bit vmcnt)
+// are ~30 GB/s at the L2 latency seen under load, and a 256-row x tile is 32 KiB per 64-column step: with ONE loader the
+// x stream, not the matrix pipe and not the weight stream, set the step time (round 6: hipcc's consumer loop and the
+// hand-scheduled one measured the same 66-68 us on the 8B gate_up at 256 rows).
+__host__ __device__ constexpr int wide_loaders_of(int nw, bool core) { return core ? 2 : wide_loaders(nw); }
+
+template <int MT, int NT, int NW, int EPI, int RING, bool PACKED, int BK = 128, bool CORE = false>
+__global__ __launch_bounds__((NW + wide_loaders_of(NW, CORE)) * 64) void linear_wide_kernel(const bf16_t* __restrict__ x,
                                                                      const bf16_t* __restrict__ w,
                                                                      void* __restrict__ out, int M, int N, int K,
                                                                      int steps, int paired_tiles, int dbg) {
@@ -94,8 +110,14 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
   constexpr int kStage = kRows * kRowB;                           // bytes per LDS stage
   // x stages: three (the loader runs two steps ahead) while they fit the 160 KiB of LDS — up to 12 row tiles at 128
   // columns per step, 16 at 64; two (one step ahead) otherwise
-  constexpr int NS = wide_stages(MT, BK);
+  // CORE (hand-scheduled consumer loop): four stages, the loader three steps ahead, and a stage is published one step
+  // EARLY — at the barrier that ends step s the tiles of steps s + 1 AND s + 2 have landed — so that the consumers can
+  // request the first fragments of step s + 1 before that barrier (their matrix pipe does not drain at step boundaries)
+  static_assert(!CORE || wide_core_shape(MT, NT, NW, BK, PACKED), "the generated core exists for this shape only");
+  static_assert(!CORE || RING == NVL_WIDE_CORE_RING, "ring depth of the generated core");
+  constexpr int NS = CORE ? NVL_WIDE_CORE_STAGES : wide_stages(MT, BK);
   constexpr int AHEAD = NS - 1;
+  constexpr int LAND = CORE ? 2 : 1;                              // steps ahead that have LANDED at a step's barrier
   static_assert(EPI != EPI_SILU || NT == 2, "SiLU: a wave holds a gate tile and its up tile");
   constexpr int GT = EPI == EPI_SILU ? 1 : NT;                    // output tiles per wave
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -143,11 +165,11 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
     // LDS chunks 64 i .. 64 i + 63 = rows 4 i + lq, slots l15; the XOR swizzle is applied on the SOURCE side (slot
     // l15 of row r holds chunk l15 ^ (r & 15)), so an instruction still reads 4 rows x 256 contiguous bytes.
     // The loads are inline asm (hipcc neither counts them nor keeps M0), so this wave's waits are explicit.
-    constexpr int NL = wide_loaders(NW);
+    constexpr int NL = wide_loaders_of(NW, CORE);
     constexpr int kPieceRows = 1024 / kRowB;                      // rows one 1-KiB LDS-DMA instruction covers: 4 (8 at BK = 64)
     constexpr int kPieces = kRows / kPieceRows;                   // 1-KiB pieces of a tile
     constexpr int kLC = kPieces / NL;                             // ... staged by THIS loader wave
-    static_assert(kPieces % NL == 0 && kLC * (AHEAD - 1) < 64, "vmcnt is a 6-bit counter");
+    static_assert(kPieces % NL == 0 && kLC * (AHEAD - LAND) < 64, "vmcnt is a 6-bit counter");
     const int lw = wave - NW;                                     // which loader: pieces lw, lw + NL, ...
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const bf16_t* xb = x + k0;
@@ -178,12 +200,14 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
                      : "memory");
       }
     };
-    // AHEAD steps in flight; "step s + 1 has landed" = at most the newest AHEAD - 1 steps' loads are still outstanding
-    issue(0);
-    if (AHEAD > 1 && steps > 1) {
-      issue(1);
-      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC * (AHEAD - 1)) : "memory");   // step 0 has landed
+    // AHEAD steps in flight; "steps up to s + LAND have landed" = at most the newest AHEAD - LAND steps' loads are still
+    // outstanding
+    if (steps >= AHEAD) {
+#pragma unroll
+      for (int a = 0; a < AHEAD; ++a) issue(a);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC * (AHEAD - LAND)) : "memory");  // steps 0 .. LAND - 1 have landed
     } else {
+      for (int a = 0; a < steps; ++a) issue(a);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_s_barrier();
@@ -191,7 +215,7 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
       // stage (s + AHEAD) % NS was last read during step s - 1: free since the previous barrier
       if (s + AHEAD <= last) {
         issue(s + AHEAD);
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC * (AHEAD - 1)) : "memory"); // step s + 1 has landed
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC * (AHEAD - LAND)) : "memory"); // steps up to s + LAND have landed
       } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -237,6 +261,29 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+  if constexpr (CORE) {
+    // ---- the whole K loop of this wave: one inline-asm statement (gemm_wide_core.inc) ------------------------------
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint64_t wb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const uint64_t p = (uint64_t)(uintptr_t)(wrow[nt] - lane * 8);           // the tile's run at this workgroup's k range
+      // (readfirstlane returns int: without the unsigned casts the low half would be SIGN-extended over the high one)
+      wb[nt] = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)(p >> 32)) << 32) |
+               (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((unsigned)p);
+    }
+    auto& flat = reinterpret_cast<f32x4_t(&)[MT * NT]>(acc);
+    const int steps_s = __builtin_amdgcn_readfirstlane(steps), rot_s = __builtin_amdgcn_readfirstlane(rot);
+    const int xa0 = (int)(lds0 + frag_off[0]), xa1 = (int)(lds0 + frag_off[1]);
+    const int wstep = dbg_no_w ? 0 : kKB * 1024;                   // bytes of a tile's packed run per k step
+#ifdef NVL_PROBES
+    if (MT == 16 && (dbg & 4)) wide_core_mt16_noread(flat, xa0, xa1, lane * 16, wb[0], wb[1], steps_s, rot_s, wstep);
+    else if (MT == 16 && (dbg & 8)) wide_core_mt16_nomfma(flat, xa0, xa1, lane * 16, wb[0], wb[1], steps_s, rot_s, wstep);
+    else
+#endif
+    if constexpr (MT == 16) wide_core_mt16(flat, xa0, xa1, lane * 16, wb[0], wb[1], steps_s, rot_s, wstep);
+    else wide_core_mt12(flat, xa0, xa1, lane * 16, wb[0], wb[1], steps_s, rot_s, wstep);
+  } else {
   u32x4_t wf[RING][NT][kKB];
   auto wload = [&](u32x4_t (*dst)[kKB], int s) {
     s = dbg_no_w ? 0 : kstep(s);
@@ -333,6 +380,7 @@ __global__ __launch_bounds__((NW + wide_loaders(NW)) * 64) void linear_wide_kern
       __syncthreads();
     }
   }
+  }  // !CORE
 
   // ---- epilogue ------------------------------------------------------------------------------------------------
 #pragma unroll
@@ -564,14 +612,14 @@ bool wide_plan(int64_t m, int n, int k, int mode, WidePlan* best) {
   return best_t < 1e30;
 }
 
-template <int MT, int NT, int NW, int EPI, bool PACKED, int BK>
+template <int MT, int NT, int NW, int EPI, bool PACKED, int BK, bool CORE = false>
 int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
-  constexpr int RING = ring_of(NT, NW, MT, BK);
-  const size_t lds = (size_t)wide_stages(MT, BK) * MT * 16 * BK * 2;
+  constexpr int RING = CORE ? NVL_WIDE_CORE_RING : ring_of(NT, NW, MT, BK);
+  const size_t lds = (size_t)(CORE ? NVL_WIDE_CORE_STAGES : wide_stages(MT, BK)) * MT * 16 * BK * 2;
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];
   if (!attr_set && lds > 64 * 1024) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK, CORE>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       nvl_set_error("nvl_linear_wide: cannot reserve %zu B of LDS", lds);
       return NVL_ELAUNCH;
@@ -587,12 +635,12 @@ int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, in
 #endif
   if (p.mgroups == 2 && pair_ok) {
     const unsigned gx = (unsigned)((p.tiles + 7) / 8) * 16;
-    hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK>), dim3(gx, p.split, 1),
-                       dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, p.tiles, dbg);
+    hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK, CORE>), dim3(gx, p.split, 1),
+                       dim3((NW + wide_loaders_of(NW, CORE)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, p.tiles, dbg);
     return NVL_OK;
   }
-  hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK>), dim3(p.tiles, p.split, p.mgroups),
-                     dim3((NW + wide_loaders(NW)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, 0, dbg);
+  hipLaunchKernelGGL((linear_wide_kernel<MT, NT, NW, EPI, RING, PACKED, BK, CORE>), dim3(p.tiles, p.split, p.mgroups),
+                     dim3((NW + wide_loaders_of(NW, CORE)) * 64), lds, s, (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, p.steps, 0, dbg);
   return NVL_OK;
 }
 
@@ -601,6 +649,10 @@ thread_local bool g_packed = false;      // weight layout of the launch being di
 template <int MT, int NT, int NW, int EPI>
 int launch_wide(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
   if constexpr (MT > 12) {                                         // the 64-column step exists for the 13-16 row-tile form only
+    if constexpr (MT == 16 && NT == 2 && NW == 3) {                 // ... whose consumer loop is the hand-scheduled core
+      static const bool core_on = env_int("NVL_WIDE_CORE", 1) != 0;  // (0: hipcc's schedule of the same decomposition, A/B)
+      if (p.bk == 64 && g_packed && core_on) return launch_wide_l<MT, NT, NW, EPI, true, 64, true>(p, x, w, out, m, n, k, s);
+    }
     if (p.bk == 64)
       return g_packed ? launch_wide_l<MT, NT, NW, EPI, true, 64>(p, x, w, out, m, n, k, s)
                       : launch_wide_l<MT, NT, NW, EPI, false, 64>(p, x, w, out, m, n, k, s);

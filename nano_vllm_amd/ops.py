@@ -16,7 +16,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnvl_hip.so")
+LIB_PATH = os.path.join(os.environ.get("NVL_LIBDIR") or os.path.join(_HERE, "lib"), "libnvl_hip.so")   # (as build.LIBDIR)
 ABI_VERSION = 6
 
 # name -> (restype, argtypes); mirrors include/nvl.h one to one (checked by tests/test_abi.py)
