@@ -84,6 +84,7 @@ __host__ __device__ constexpr int wide_loaders(int nw) { return nw == 4 ? 2 : 1;
 // The hand-scheduled consumer K loop (inline asm, generated: tools/gen_wide_asm.py describes the schedule) for the
 // one-wave-per-SIMD shape NT = 2, NW = 3, 64-column k steps, tile-packed weights, 12 or 16 row tiles.
 #include "gemm_wide_core.inc"
+#include "gemm_tile4_core.inc"
 #ifdef NVL_PROBES
 #include "gemm_wide_core_probes.inc"       // (generated by the probe build: the loop without its reads / without its MFMAs)
 #endif
@@ -407,6 +408,218 @@ __global__ __launch_bounds__((NW + wide_loaders_of(NW, CORE)) * 64) void linear_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FOUR-consumer tile kernel (round 6) for 145-256 rows on tile-packed weights: every SIMD of the CU runs a matrix wave.
+// The one-wave-per-SIMD kernel above leaves a SIMD to its loader wave and streams W through the consumers' registers; its
+// matrix work (3 SIMDs, 17 cycles per 16x16x32 MFMA at the ~1.9 GHz the chip holds under this load) is 37 us on the 8B
+// gate_up at 256 rows before a byte is waited for (profiles/r06_gemm_core_streams_*.txt: 42 us measured for the MFMA-only
+// loop, 48 with the fragment reads, 60 with both streams). Here:
+//   waves 0-3  consumers: wave q owns RT row tiles (rows 64 q ...) x ALL CT column tiles of the workgroup; both operands
+//              come from LDS (gemm_tile4_core.inc, generated by tools/gen_wide_asm.py — its GenTile docstring is the
+//              schedule); <= 256 registers, so seven waves fit the CU;
+//   waves 4-5  x loaders: the [RT x 64 rows][64 columns] tile of step s + 4 by LDS-DMA into a 4-stage ring, every other
+//              1-KiB piece each (one wave's 63 loads in flight are ~30 GB/s);
+//   waves 6-7  W loaders: CT x 2 KiB of packed fragments per step (wave 6 the first k block of every tile, wave 7 the
+//              second), HBM -> their OWN register rings (6-8 steps deep: that is where the HBM latency is hidden — 160 KiB
+//              of LDS cannot hold four x stages AND a deep W ring) -> ds_write_b128 into a 2-stage LDS ring one step ahead
+//              of the consumers.
+// Two barriers per 64-column step (an s_barrier costs the matrix pipe nothing when the MFMAs queue behind it:
+// tools/probes/mfma_issue_probe.hip): a(s) after the first k block = "x(s + 1), W(s + 1) are in LDS", b(s) after the second
+// = "every read of x(s) / W(s) has returned".
+constexpr int kT4XStages = 4, kT4WStages = 2;
+__host__ __device__ constexpr int tile4_wring(int ct) { return ct <= 6 ? 8 : 6; }   // W register ring (k steps) of a W loader: <= 192 registers
+
+template <int RT, int CT, int EPI>
+__global__ __launch_bounds__(8 * 64) void linear_tile4_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                              void* __restrict__ out, int M, int N, int K, int steps, int dbg) {
+#ifdef NVL_PROBES
+  const bool dbg_no_x = dbg & 1, dbg_no_w = dbg & 2;              // (probe builds: NVL_WIDE_DBG, as linear_wide_kernel)
+#else
+  constexpr bool dbg_no_x = false, dbg_no_w = false;
+  (void)dbg;
+#endif
+  constexpr int kRows = RT * 64;                                  // rows of an x stage (four waves x RT row tiles)
+  constexpr int kXStage = kRows * 128;                            // bytes: 64 columns per step
+  constexpr int kWStage = CT * 2048;
+  constexpr int HC = CT / 2;                                      // SiLU: gate tiles 0 .. HC - 1, their up tiles HC .. CT - 1
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* wlds = smem + kT4XStages * kXStage;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int tile_x = blockIdx.x;
+  const int out_cols = EPI == EPI_SILU ? N / 2 : N;
+  const int ntiles = out_cols >> 4;
+  const int64_t k0 = (int64_t)blockIdx.y * steps * 64;
+  const int last = steps - 1;
+  const int rot = (int)(((unsigned)tile_x + 3u * blockIdx.y) % (unsigned)steps);   // (as linear_wide_kernel: staggered K walks)
+  auto kstep = [&](int s) {
+    s = (s < last ? s : last) + rot;
+    return s >= steps ? s - steps : s;
+  };
+  // W tile (16 weight rows) behind column tile c of this workgroup; past the ragged end: any valid tile, masked at the store
+  auto wtile = [&](int c) {
+    int t = EPI == EPI_SILU ? tile_x * HC + (c % HC) : tile_x * CT + c;
+    t = t < ntiles ? t : ntiles - 1;
+    return EPI == EPI_SILU && c >= HC ? t + ntiles : t;
+  };
+
+  if (wave >= 6) {
+    // ---- W loaders: wave 6 + kb takes k block kb of every tile ---------------------------------------------------------
+    constexpr int RW = tile4_wring(CT), P = CT;                   // ring depth (steps), 1-KiB pieces per step and loader
+    const int kb = wave - 6;
+    const bf16_t* src[CT];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) src[c] = w + (int64_t)wtile(c) * 16 * K + ((k0 >> 5) + kb) * 512 + lane * 8;
+    u32x4_t ring[RW][P];
+    auto load = [&](u32x4_t* dst, int s) {
+      const int ks = dbg_no_w ? 0 : kstep(s);
+#pragma unroll
+      for (int c = 0; c < CT; ++c)
+        dst[c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(src[c] + ks * 1024));
+    };
+    auto park = [&](const u32x4_t* set, int s) {                  // registers -> LDS stage s % 2, lane-linear (fragment order)
+#ifdef NVL_PROBES
+      if (dbg & 4) return;                                        // (probe: no ds_writes)
+#endif
+      unsigned char* dst = wlds + (s & 1) * kWStage + kb * 1024 + lane * 16;
+#pragma unroll
+      for (int c = 0; c < CT; ++c) *reinterpret_cast<u32x4_t*>(dst + c * 2048) = set[c];
+    };
+#pragma unroll
+    for (int r = 0; r < RW - 1; ++r) load(ring[r], r);
+    park(ring[0], 0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the ds_writes have landed (NOT vmcnt: the ring stays in flight)
+    __builtin_amdgcn_s_barrier();
+    // RW steps of straight-line code per iteration (unconditional, index-clamped loads: hipcc's vmcnt stays counted, as in
+    // linear_wide_kernel's consumer loop); the steps % RW tail runs on the sets already requested
+    const int nblk = steps / RW;
+    for (int blk = 0; blk < nblk; ++blk) {
+#pragma unroll
+      for (int i = 0; i < RW; ++i) {
+        const int s = blk * RW + i;
+        load(ring[(i + RW - 1) % RW], s + RW - 1);
+        park(ring[(i + 1) % RW], s + 1);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                             // a(s): W(s + 1) is in LDS
+        __builtin_amdgcn_s_barrier();                             // b(s)
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < RW - 1; ++i) {
+      if (nblk * RW + i < steps) {
+        park(ring[(i + 1) % RW], nblk * RW + i + 1);              // (past the last step: a clamped set, never read)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    return;
+  }
+  if (wave >= 4) {
+    // ---- x loaders (as linear_wide_kernel's, 64-column steps): pieces lw, lw + 2, ... of the tile ----------------------
+    constexpr int kPieces = kRows / 8, kLC = kPieces / 2;
+    static_assert(kPieces % 2 == 0 && 3 * kLC < 64, "vmcnt is a 6-bit counter");
+    const int lw = wave - 4;
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const bf16_t* xb = x + k0;
+    int x_src[kLC];
+#pragma unroll
+    for (int i = 0; i < kLC; ++i) {
+      const int prow = lane >> 3, slot = lane & 7;
+      const int row = 8 * (i * 2 + lw) + prow;
+      int grow = row < M ? row : M - 1;                           // padding rows read a valid row (never stored)
+      x_src[i] = grow * K + ((slot ^ ((row >> 1) & 7)) << 3);
+    }
+    auto issue = [&](int s) {
+      if (dbg_no_x && s > 0) return;
+      const unsigned dst = lds0 + (unsigned)(s % kT4XStages) * kXStage + (unsigned)lw * 1024;
+      const bf16_t* srcp = xb + kstep(s) * 64;
+#pragma unroll
+      for (int i = 0; i < kLC; ++i) {
+#ifdef NVL_PROBES
+        if ((dbg & 32) && (i & 1)) continue;                      // (probe: half the pieces — is the loader ISSUE-bound?)
+#endif
+        unsigned keep;
+        const unsigned d = __builtin_amdgcn_readfirstlane(dst + i * 2048);
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(srcp + x_src[i]), "s"(d)
+                     : "memory");
+      }
+    };
+    const int first = steps < kT4XStages ? steps : kT4XStages;
+    for (int a = 0; a < first; ++a) issue(a);
+    if (first >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kLC) : "memory");           // x(0) has landed
+    else if (first == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kLC) : "memory");
+    else if (first == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < steps; ++s) {
+      // x(s + 1) has landed = only the tiles behind it (at most x(s + 2), x(s + 3)) may still be on their way
+      const int rem = last - (s + 1);
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kLC) : "memory");
+      else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                               // a(s)
+      __builtin_amdgcn_s_barrier();                               // b(s): stage s % 4 is free
+      if (s + kT4XStages <= last) issue(s + kT4XStages);
+    }
+    return;
+  }
+
+  // ---- consumers ---------------------------------------------------------------------------------------------------
+  f32x4_t acc[RT * CT];
+#pragma unroll
+  for (int i = 0; i < RT * CT; ++i) acc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  {
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned wl0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)wlds;
+    // B fragment of k block kb: row l15 of a row tile, 16-byte slot swizzled with the row pair (the loaders' image)
+    const int f0 = l15 * 128 + (((0 * 4 + lq) ^ ((l15 >> 1) & 7)) << 4), f1 = l15 * 128 + (((1 * 4 + lq) ^ ((l15 >> 1) & 7)) << 4);
+    const int xrow0 = wave * RT * 2048;                           // this wave's first row tile inside a stage
+    const int steps_s = __builtin_amdgcn_readfirstlane(steps);
+#define NVL_T4_CORE(R_, C_) if constexpr (RT == R_ && CT == C_) tile4_core_r##R_##c##C_(acc, (int)(lds0 + xrow0 + f0), (int)(lds0 + xrow0 + f1), (int)(wl0 + lane * 16), steps_s);
+#ifdef NVL_PROBES
+    if (RT == 4 && CT == 6 && (dbg & 24)) {
+      if constexpr (RT == 4 && CT == 6) {
+        if (dbg & 8) tile4_core_r4c6_noread(acc, (int)(lds0 + xrow0 + f0), (int)(lds0 + xrow0 + f1), (int)(wl0 + lane * 16), steps_s);
+        else tile4_core_r4c6_nomfma(acc, (int)(lds0 + xrow0 + f0), (int)(lds0 + xrow0 + f1), (int)(wl0 + lane * 16), steps_s);
+      }
+    } else
+#endif
+    {
+    NVL_T4_CORE(4, 6) NVL_T4_CORE(4, 8) NVL_T4_CORE(4, 4) NVL_T4_CORE(3, 6) NVL_T4_CORE(3, 8) NVL_T4_CORE(3, 4)
+    }
+#undef NVL_T4_CORE
+  }
+  // ---- epilogue: lane (l15, lq) holds out[row = 16 rt + l15][col = tile + 4 lq .. + 3] ---------------------------------
+#pragma unroll
+  for (int r = 0; r < RT; ++r) {
+    const int m = (wave * RT + r) * 16 + l15;
+    if (m >= M) continue;
+#pragma unroll
+    for (int c = 0; c < (EPI == EPI_SILU ? HC : CT); ++c) {
+      const int n = (EPI == EPI_SILU ? tile_x * HC + c : tile_x * CT + c) * 16;
+      if (n >= out_cols) continue;
+      if constexpr (EPI == EPI_SILU) {
+        const f32x4_t g = acc[r * CT + c], u = acc[r * CT + c + HC];
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = silu_f32(round_bf16(g[j])) * round_bf16(u[j]);
+        u32x2_t ov = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+        *reinterpret_cast<u32x2_t*>((bf16_t*)out + (int64_t)m * out_cols + n + lq * 4) = ov;
+      } else if constexpr (EPI == EPI_BF16) {
+        const f32x4_t v = acc[r * CT + c];
+        u32x2_t o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *reinterpret_cast<u32x2_t*>((bf16_t*)out + (int64_t)m * N + n + lq * 4) = o;
+      } else {
+        *reinterpret_cast<f32x4_t*>((float*)out + ((int64_t)blockIdx.y * M + m) * N + n + lq * 4) = acc[r * CT + c];
+      }
+    }
+  }
+}
+
 // out = epilogue(sum_s part[s]) for bf16 / SiLU outputs whose GEMM was split over K: 4 output columns per thread,
 // every slab piece requested before the first add (one memory round trip); slabs are summed in split order.
 template <int EPI>
@@ -645,6 +858,73 @@ int launch_wide_l(const WidePlan& p, const void* x, const void* w, void* out, in
 }
 
 thread_local bool g_packed = false;      // weight layout of the launch being dispatched (set by nvl_linear_wide)
+thread_local int g_mode = 0;             // ... and its output mode (a split-K bf16 / SiLU call dispatches the PARTIAL kernels)
+
+// ---- four-consumer tile kernel: when, and with how many column tiles per workgroup ---------------------------------------
+// One row group of 10-16 row tiles on tile-packed weights. The K split is the plan's (nvl_linear_wide_plan reports it without
+// knowing the layout); the column tiles per workgroup are chosen for whole rounds of 256 workgroups: fewer, fatter workgroups
+// re-read x less often but a ragged last round costs a full one (Qwen3-32B gate_up: 534 workgroups of 6 tiles = 3 rounds,
+// 400 of 8 = 2).
+// Where it is used (round-6 A/B of every Qwen3-8B / 14B / 32B projection at 160 / 192 / 208 / 256 rows against the
+// one-wave-per-SIMD kernel, profiles/r06_gemm_tile4_ab_all_shapes.json): bf16 and SiLU outputs — at 145-192 rows always
+// (+2 ... +25 %: 32B gate_up 150 vs 190 us, per-rank TP gate_up 33 vs 38), at 193-256 rows when its whole-round count beats
+// the 96-column tiling's (32B gate_up 191 vs 222 us, qkv 48.5 vs 49.4); the fp32-slab projections (o / down: small N, deep
+// split K) are a wash or lose (8B down at 192 rows 48.8 vs 41.2) and keep the kernel above. NVL_WIDE_TILE4=0 / 2 = never /
+// wherever it can run; NVL_WIDE_CT forces the column tiles.
+int tile4_ct(const WidePlan& p, int mode, int n, int k) {
+  const int on = env_int("NVL_WIDE_TILE4", 1), force_ct = env_int("NVL_WIDE_CT", 0);   // (host side of a launch: read per call)
+  if (!on || !g_packed || p.mgroups != 1 || (p.mt != 12 && p.mt != 16) || k % 64) return 0;
+  if (on != 2 && g_mode == EPI_PARTIAL) return 0;
+  const int units = (mode == EPI_SILU ? n / 2 : n) / 16;           // column tiles of the output (SiLU: gate / up pairs)
+  int best = 0;
+  double best_t = 1e30;
+  for (int ct : {8, 6, 4}) {
+    if (force_ct && ct != force_ct) continue;
+    const int per_wg = mode == EPI_SILU ? ct / 2 : ct;
+    const int64_t wgs = (int64_t)((units + per_wg - 1) / per_wg) * p.split;
+    const double t = (double)((wgs + 255) / 256) * (0.15 + 0.075 * ct);   // us per 64-column step of a workgroup, roughly
+    if (t < best_t) { best_t = t; best = ct; }
+  }
+  if (on != 2 && p.mt == 16) {
+    // ... against the shipped tiling of the same plan (nw x nt x 16 columns per workgroup, ~ a 6-tile workgroup's step)
+    const double t_wide = (double)(((int64_t)p.tiles * p.split + 255) / 256) * 0.57;
+    if (best_t >= t_wide) return 0;
+  }
+  return best;
+}
+
+template <int RT, int CT, int EPI>
+int launch_tile4(const WidePlan& p, int mode, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
+  const size_t lds = (size_t)kT4XStages * RT * 64 * 128 + (size_t)kT4WStages * CT * 2048;
+  static bool attr_done[NVL_MAX_DEVICES] = {};
+  bool& attr_set = attr_done[nvl_device_slot()];
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile4_kernel<RT, CT, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) {
+      nvl_set_error("nvl_linear_wide: cannot reserve %zu B of LDS", lds);
+      return NVL_ELAUNCH;
+    }
+    attr_set = true;
+  }
+  const int units = (EPI == EPI_SILU ? n / 2 : n) / 16, per_wg = EPI == EPI_SILU ? CT / 2 : CT;
+#ifdef NVL_PROBES
+  static const int dbg = env_int("NVL_WIDE_DBG", 0);
+#else
+  constexpr int dbg = 0;
+#endif
+  hipLaunchKernelGGL((linear_tile4_kernel<RT, CT, EPI>), dim3((unsigned)((units + per_wg - 1) / per_wg), p.split, 1), dim3(8 * 64), lds, s,
+                     (const bf16_t*)x, (const bf16_t*)w, out, (int)m, n, k, (k / 64) / p.split, dbg);
+  return NVL_OK;
+}
+
+template <int EPI>
+int dispatch_tile4(int ct, const WidePlan& p, int mode, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
+#define NVL_T4(R_, C_) if (p.mt == R_ * 4 && ct == C_) return launch_tile4<R_, C_, EPI>(p, mode, x, w, out, m, n, k, s);
+  NVL_T4(4, 8) NVL_T4(4, 6) NVL_T4(4, 4) NVL_T4(3, 8) NVL_T4(3, 6) NVL_T4(3, 4)
+#undef NVL_T4
+  nvl_set_error("nvl_linear_wide: internal plan error (tile4 mt=%d ct=%d)", p.mt, ct);
+  return NVL_EINVAL;
+}
 
 template <int MT, int NT, int NW, int EPI>
 int launch_wide(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
@@ -683,6 +963,7 @@ int dispatch_mt(const WidePlan& p, const void* x, const void* w, void* out, int6
 
 template <int EPI>
 int dispatch_wide(const WidePlan& p, const void* x, const void* w, void* out, int64_t m, int n, int k, hipStream_t s) {
+  if (const int ct = tile4_ct(p, EPI, n, k)) return dispatch_tile4<EPI>(ct, p, EPI, x, w, out, m, n, k, s);
 #define NVL_W_CASE(NT_, NW_) \
   if (p.nt == NT_ && p.nw == NW_) return dispatch_mt<NT_, NW_, EPI>(p, x, w, out, m, n, k, s);
   if constexpr (EPI != EPI_SILU) { NVL_W_CASE(1, 3) NVL_W_CASE(1, 4) }
@@ -720,6 +1001,7 @@ extern "C" int nvl_linear_wide(const void* x, const void* weight, void* out, int
   NVL_REQUIRE(mode >= 0 && mode <= 2, "nvl_linear_wide: mode=%d (0 bf16, 1 silu*mul, 2 split-K fp32 partials)", mode);
   NVL_REQUIRE(weight_layout == 0 || weight_layout == 1, "nvl_linear_wide: weight_layout=%d (0 row-major [N, K], 1 tile-packed)", weight_layout);
   g_packed = weight_layout == 1;
+  g_mode = mode;
   NVL_REQUIRE(((uintptr_t)x | (uintptr_t)weight | (uintptr_t)out | (uintptr_t)workspace) % 16 == 0,
               "nvl_linear_wide: pointers must be 16-byte aligned");
   WidePlan p;

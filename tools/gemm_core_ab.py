@@ -19,7 +19,7 @@ def child(ms):
     ops.load_library()
     BF16 = torch.bfloat16
     only = os.environ.get("SWEEP_SHAPES")
-    force = os.environ.get("CORE_AB_FORCE", "1") == "1"
+    force = os.environ.get("CORE_AB_FORCE", "0") == "1"
     if force:                                    # the decomposition the core exists for, on every shape
         os.environ["NVL_WIDE_NT"], os.environ["NVL_WIDE_NW"] = "2", "3"
     res = {}
@@ -55,7 +55,7 @@ def child(ms):
                     ops.linear_wide(x, w, mode, out=out, workspace=scratch, packed=True)
             t = timeit(ours) / len(pk)
             t_blas = None
-            if os.environ.get("NVL_WIDE_CORE", "1") != "0":
+            if os.environ.get("CORE_AB_BLAS") == "1":
                 def blas():
                     for w in ws:
                         y = F.linear(x, w)
@@ -68,22 +68,31 @@ def child(ms):
     print(json.dumps(res))
 
 
+ARMS = {"tile4": {"CORE_AB_BLAS": "1"},                                   # the default: four-consumer tile kernel where it applies
+        "core": {"NVL_WIDE_TILE4": "0"},                                  # one-wave-per-SIMD kernel, hand-scheduled consumer loop
+        "hipcc": {"NVL_WIDE_TILE4": "0", "NVL_WIDE_CORE": "0"}}           # ... hipcc's schedule of it (the round-5 kernel)
+
+
 def main():
     ms = [a for a in sys.argv[1:] if a.isdigit()] or ["208", "256"]
     arms = {}
-    for core in ("1", "0"):
-        env = dict(os.environ, NVL_WIDE_CORE=core, CORE_AB_CHILD="1")
+    for name, extra in ARMS.items():
+        env = dict(os.environ, CORE_AB_CHILD="1", **extra)
         p = subprocess.run([sys.executable, os.path.abspath(__file__), *ms], env=env, capture_output=True, text=True)
-        sys.stderr.write(p.stderr[-3000:])
         line = [l for l in p.stdout.splitlines() if l.startswith("{")]
-        arms[core] = json.loads(line[-1]) if line else {"error": p.stderr[-800:]}
+        arms[name] = json.loads(line[-1]) if line else {"error": p.stderr[-800:]}
     out = {}
-    for key, a in arms["1"].items():
-        b = arms["0"].get(key) if isinstance(arms["0"], dict) else None
-        if not isinstance(a, dict) or not isinstance(b, dict):
+    for key, a in arms["tile4"].items():
+        if not isinstance(a, dict):
             continue
-        out[key] = dict(core_us=a["us"], hipcc_us=b["us"], blas_us=a["blas_us"], same_bits=a["sha"] == b["sha"],
-                        relerr=a["relerr"], split=a["split"])
+        row = dict(tile4_us=a["us"], blas_us=a["blas_us"], relerr=a["relerr"], split=a["split"])
+        for other in ("core", "hipcc"):
+            b = arms[other].get(key)
+            if isinstance(b, dict):
+                row[other + "_us"] = b["us"]
+                row[other + "_relerr"] = b["relerr"]
+        row["core_same_bits_as_hipcc"] = (arms["core"].get(key) or {}).get("sha") == (arms["hipcc"].get(key) or {}).get("sha")
+        out[key] = row
     print(json.dumps(dict(arms_error={k: v.get("error") for k, v in arms.items() if "error" in v}, shapes=out)))
 
 
