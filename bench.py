@@ -176,7 +176,7 @@ def main():
     if with_extras:
         # The headline is SAFE before any extra starts: the complete line (without `extra_configs`) goes to stderr and
         # to gpurun_out/bench_headline.json now; stdout still carries exactly ONE JSON line, printed at the end, and
-        # an extra that no longer fits the run's wall budget (NVL_BENCH_WALL_BUDGET, default 250 s) is skipped.
+        # an extra that no longer fits the run's wall budget (NVL_BENCH_WALL_BUDGET, default 285 s) is skipped.
         keep_headline(result)
         result["extra_configs"] = extra_configs(args, torch)
     if rank == 0:
@@ -479,21 +479,21 @@ def extra_configs(args, torch) -> dict:
     # name -> (arguments, seconds the child took on the round's boxes incl. engine start). BASELINE's own configs first,
     # then the per-rank engines: an extra whose expected time does not fit into what is left of the wall budget is skipped.
     runs = {"config3": (["--model", "qwen3-8b", "--workload", "prefix", "--warmup", "1"], 13),
-            # what ONE rank of the TP = 8 / TP = 4 engine computes, run as a TP = 1 engine: a rank's kernels without any
-            # collective => an UPPER BOUND per rank, not a TP measurement
-            "tp8_rank_shape_bench": (["--model", "qwen3-32b-tp8rank", "--tp", "1", "--warmup", "0"], 20),
             # BASELINE config 4's single-GPU anchor: Qwen3-32B on the bench workload at TP = 1 — what a later
             # `--gpus N` line's tp_qwen3_32b divides by
             "config4_anchor": (["--model", "qwen3-32b", "--tp", "1", "--warmup", "0"], 48),
             "config5": (["--model", "qwen3-32b", "--tp", "1", "--workload", "long", "--max-num-seqs", "16", "--warmup", "0"], 30),
+            # what ONE rank of the TP = 8 / TP = 4 engine computes, run as a TP = 1 engine: a rank's kernels without any
+            # collective => an UPPER BOUND per rank, not a TP measurement (both quoted in BASELINE.md next to the anchor)
+            "tp8_rank_shape_bench": (["--model", "qwen3-32b-tp8rank", "--tp", "1", "--warmup", "0"], 20),
             "tp4_rank_shape_bench": (["--model", "qwen3-32b-tp4rank", "--tp", "1", "--warmup", "0"], 23),
             "tp8_rank_shape_16k_prompts": (["--model", "qwen3-32b-tp8rank", "--tp", "1", "--workload", "long",
                                             "--max-num-seqs", "16", "--warmup", "1"], 44)}
     per_child = float(os.environ.get("NVL_BENCH_EXTRA_TIMEOUT", "300"))
     # the WHOLE run (engine start, warm-up and timed passes, roofline replay, CPU baseline, extras) aims at this wall time:
-    # with the driver's 20 + 5 passes the headline part takes ~140 s, and the four extras that fit are BASELINE's configs
-    # and the TP = 8 rank shape; the default 1 + 1 run has room for all six (profiles/r05_final_bench.json)
-    budget = float(os.environ.get("NVL_BENCH_WALL_BUDGET", "250"))
+    # with the driver's 20 + 5 passes the headline part takes ~140 s, and the five extras that fit are BASELINE's configs and
+    # the two rank shapes (every number BASELINE.md quotes); the default 1 + 1 run has room for all six
+    budget = float(os.environ.get("NVL_BENCH_WALL_BUDGET", "285"))
     env = dict(os.environ, OMP_NUM_THREADS="8")    # the children's host loops
     for name, (extra, expected_s) in runs.items():
         t0 = time.perf_counter()

@@ -170,3 +170,12 @@ def test_ops_refuse_cpu_tensors():
     x = torch.zeros(4, 1024, dtype=torch.bfloat16)
     with pytest.raises(ops.NvlError, match="no CPU fallback"):
         ops.rmsnorm(x, torch.ones(1024, dtype=torch.bfloat16), 1e-6)
+
+
+def test_generated_asm_cores_are_fresh():
+    """csrc/gemm_wide_core.inc and gemm_tile4_core.inc are GENERATED (tools/gen_wide_asm.py is the schedule); the committed
+    files must be what the generator writes."""
+    import subprocess
+    import sys
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_wide_asm.py"), "--check"]).returncode
+    assert rc == 0, "run `python tools/gen_wide_asm.py` and commit the .inc files"

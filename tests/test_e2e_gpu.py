@@ -402,6 +402,7 @@ def test_qwen3_06b_width_eager_logits_within_one_floor_of_the_cpu_oracle(ckpt_06
     _check("0.6B width, eager, logits captured (CPU oracle)", v, sum(max_tokens))
 
 
+@pytest.mark.slow      # (35 s; the T = 0.6 twin below — the path the bench runs — and the greedy 0.6B cases above stay in the default suite)
 def test_config2_shaped_batch_greedy_parity_vs_device_oracle(ckpt_06b):
     """BASELINE.json config 2's regime at Qwen3-0.6B width: 64 sequences with the bench's ragged prompt lengths
     (100-1024 tokens, ids < 10,000, seeded like the reference bench.py), 33 output tokens each => three 16,384-token

@@ -615,7 +615,8 @@ def test_paged_attn_decode_fused_refuses_slabs_for_the_packed_dot_kernel(ops):
                                     torch.ones(1, dtype=torch.int32, device="cuda"), 8, 0.1, 256, ws)
 
 
-@pytest.mark.parametrize("hq,hkv", [(16, 8), (16, 2), (8, 1), (32, 8), (40, 8), (20, 4), (5, 1), (24, 8)])
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (16, 2), (8, 1), (32, 8), (40, 8), pytest.param(20, 4, marks=pytest.mark.slow),
+                                    pytest.param(5, 1, marks=pytest.mark.slow), pytest.param(24, 8, marks=pytest.mark.slow)])
 def test_paged_attn_decode_large_batch(ops, hq, hkv):
     """bench-like shape: batch 256, contexts 100..2048; group size 2 (Qwen3-0.6B), 8 with two / one kv heads
     (Qwen3-32B per-rank shapes at TP = 4 / 8: the matrix-core decode kernel), 4 (Qwen3-8B)."""
@@ -806,6 +807,7 @@ def test_prefill_paged_continuation_of_a_prompt_longer_than_the_token_budget(ops
     assert err <= 2e-2 * o_ref.float().abs().max().item() + 1e-3, err
 
 
+@pytest.mark.slow      # (19 s: re-runs the prefill tests of this file in a child process with the other workgroup shape forced)
 def test_prefill_other_workgroup_shape_passes_the_same_tests():
     """The prefill kernel exists in two workgroup shapes (4 waves = one q-head, 8 waves = two q-heads of a kv group
     sharing the staged K/V tile), chosen per launch by max_seqlen_q unless NVL_PREFILL_WAVES forces one: run the oracle

@@ -153,8 +153,8 @@ def _comm_worker(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world", [2, 4])
-def test_p2p_collectives_between_processes(world):
+@pytest.mark.parametrize("world", [2, pytest.param(4, marks=pytest.mark.slow)])     # (4 processes time-slice ONE GPU: ~60 s; the
+def test_p2p_collectives_between_processes(world):                                   #  TP = 4 engine test drives the same kernels)
     """(W = 8 — kMaxWorld ranks, 64-element column slices — runs inside the TP = 8 engine test below: its
     tp.init_p2p stress self-check drives the one-shot, two-shot, fused-norm, gather and captured-graph forms of these
     kernels between eight processes. This standalone sweep with eight processes time-slicing the ONE GPU does not
@@ -260,7 +260,7 @@ def test_tp2_engine_sampled_T06_parity_draws_replayed_on_one_gpu(tiny_ckpt, monk
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("tp_size", [4, 8])
+@pytest.mark.parametrize("tp_size", [4, pytest.param(8, marks=pytest.mark.slow)])   # (eight ranks on ONE GPU: ~20 s; same code as 4)
 def test_tp4_tp8_engine_greedy_parity_on_one_gpu(tp_size, monkeypatch):
     """The whole TP engine at degrees 4 and 8 (every rank a process on cuda:0): a 16 / 8-head model shards down to
     4 / 2 query heads and 2 / 1 kv heads per rank (models/qwen3.py:29-38 at TP = 8), the vocabulary into 8 shards whose
