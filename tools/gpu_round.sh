@@ -232,6 +232,38 @@ pmcwaits)
   # wave-cycle split of the prefill-attention kernel (same counters as profiles/r03_prefill_pmc_waits.json)
   (cd /tmp && rm -rf /tmp/pmc_pf_waits && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_pf_waits -o pf -- python $REPO/tools/prefill_bench.py > $OUT/prefill_under_pmc_waits.json 2> $OUT/prefill_pmc_waits.err; echo "pmcwaits rc=$?"; tail -c 300 $OUT/prefill_pmc_waits.err)
   f=$(find /tmp/pmc_pf_waits -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_group_summary.py $f prefill_attn $OUT/prefill_pmc_waits.json | tail -5;;
+first8)
+  # FIRST CONTACT with a multi-GPU node, unattended, most valuable evidence first (every sub-step has its own timeout; a
+  # failure never stops the sequence). NGPUS=n (default: every visible GPU). FIRST8_DRY=1 = the one-GPU stand-in: 2 ranks
+  # on GPU 0 with disjoint CU halves, gloo, Qwen3-0.6B shapes — checks that the sequence itself runs.
+  #   1. tp.init_p2p's hand-off decision on the real links + P2P all-reduce us vs RCCL at the decode sizes (131 x 5120 ...)
+  #   2. bench.py --model qwen3-32b --tp 2 / 4 / 8 (BASELINE's second metric; falls back to RCCL by itself if P2P latches)
+  #   3. one rocprofv3 kernel trace of a TP = N decode-heavy pass (timeline of a decode step: where the collectives sit)
+  N=${NGPUS:-$(python -c "import torch; print(torch.cuda.device_count())")}
+  if [ "${FIRST8_DRY:-0}" = 1 ]; then
+    export NVL_BENCH_SHARE_GPU=1 NVL_BENCH_BACKEND=gloo NVL_BENCH_CU_SPLIT=1; N=2; MODEL=qwen3-0.6b; SEQS="--num-seqs 32 --num-kvcache-blocks 200"; P2PMODE=""
+  else
+    MODEL=qwen3-32b; SEQS=""; P2PMODE="--multi-gpu"
+  fi
+  echo "first8: $N ranks, model $MODEL, dry=${FIRST8_DRY:-0}"
+  timeout 600 python tools/p2p_bench.py $N $P2PMODE > $OUT/first8_p2p_vs_rccl_w$N.json 2> $OUT/first8_p2p.err; echo "first8 p2p rc=$?"; tail -c 300 $OUT/first8_p2p.err | grep -v amdgpu.ids; cut -c1-1500 $OUT/first8_p2p_vs_rccl_w$N.json
+  for t in 2 4 8; do
+    [ $t -gt $N ] && continue
+    T0=$(date +%s); timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $t --master-addr 127.0.0.1 --master-port $((29600 + t)) bench.py --gpus $t --tp $t --model $MODEL --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs $SEQS > $OUT/first8_tp$t.json 2> $OUT/first8_tp$t.err; echo "first8 tp=$t rc=$? wall=$(( $(date +%s) - T0 )) s"
+    grep -v "socket.cpp\|Gloo\|amdgpu.ids\|OMP_NUM\|\*\*\*" $OUT/first8_tp$t.err | tail -4; python - $OUT/first8_tp$t.json <<'PY'
+import json, sys
+try:
+    d = json.loads([ln for ln in open(sys.argv[1]) if ln.startswith("{")][-1])
+    c = d["config"]
+    print("  value", d.get("value"), d.get("unit"), "| p2p", c.get("p2p_collectives"), c.get("p2p_handoff"), c.get("p2p_status"), "| attempt", d.get("tp_p2p_attempt"))
+except Exception as ex:
+    print("  no line:", repr(ex))
+PY
+  done
+  (cd /tmp && rm -rf /tmp/prof_first8 && timeout 900 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_first8 -o tp -- python -m torch.distributed.run --nnodes=1 --nproc-per-node $N --master-addr 127.0.0.1 --master-port 29650 $REPO/bench.py --gpus $N --tp $N --model $MODEL --steps 1 --warmup 0 --no-cpu-baseline --no-extra-configs --no-roofline --num-seqs 32 ${SEQS#--num-seqs 32} > $OUT/first8_under_rocprof.json 2> $OUT/first8_prof.err; echo "first8 prof rc=$?")
+  for f in $(find /tmp/prof_first8 -name '*kernel_stats.csv' | head -$N); do cp $f $OUT/first8_kernel_stats_$(basename $(dirname $f)).csv; done
+  f=$(find /tmp/prof_first8 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && head -14 $f | cut -c1-160
+  unset NVL_BENCH_SHARE_GPU NVL_BENCH_BACKEND NVL_BENCH_CU_SPLIT;;
 *) echo "unknown step $w";;
 esac
 done
