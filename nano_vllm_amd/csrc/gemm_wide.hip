@@ -498,10 +498,10 @@ __global__ __launch_bounds__(8 * 64) void linear_tile4_kernel(const bf16_t* __re
 #pragma unroll
       for (int i = 0; i < RW; ++i) {
         const int s = blk * RW + i;
-        load(ring[(i + RW - 1) % RW], s + RW - 1);
         park(ring[(i + 1) % RW], s + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                             // a(s): W(s + 1) is in LDS
+        load(ring[(i + RW - 1) % RW], s + RW - 1);                // (requests go out in the half step nobody waits for this wave)
         __builtin_amdgcn_s_barrier();                             // b(s)
       }
     }
@@ -531,12 +531,14 @@ __global__ __launch_bounds__(8 * 64) void linear_tile4_kernel(const bf16_t* __re
       int grow = row < M ? row : M - 1;                           // padding rows read a valid row (never stored)
       x_src[i] = grow * K + ((slot ^ ((row >> 1) & 7)) << 3);
     }
-    auto issue = [&](int s) {
+    // pieces [i0, i1) of this loader's share of tile s
+    auto issue = [&](int s, int i0, int i1) {                     // (wave-uniform bounds; the piece loop stays unrolled)
       if (dbg_no_x && s > 0) return;
       const unsigned dst = lds0 + (unsigned)(s % kT4XStages) * kXStage + (unsigned)lw * 1024;
       const bf16_t* srcp = xb + kstep(s) * 64;
 #pragma unroll
       for (int i = 0; i < kLC; ++i) {
+        if (i < i0 || i >= i1) continue;
 #ifdef NVL_PROBES
         if ((dbg & 32) && (i & 1)) continue;                      // (probe: half the pieces — is the loader ISSUE-bound?)
 #endif
@@ -548,22 +550,27 @@ __global__ __launch_bounds__(8 * 64) void linear_tile4_kernel(const bf16_t* __re
                      : "memory");
       }
     };
-    const int first = steps < kT4XStages ? steps : kT4XStages;
-    for (int a = 0; a < first; ++a) issue(a);
-    if (first >= 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * kLC) : "memory");           // x(0) has landed
-    else if (first == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kLC) : "memory");
+    static_assert(kLC % 2 == 0, "a tile is issued in two halves");
+    // Tile s + 3 goes out in TWO halves, one behind each barrier of step s (its stage, (s - 1) % 4, is free since b(s - 1)):
+    // issuing a whole tile between b(s) and a(s + 1) — half a step — made the loaders the last to arrive at a(s + 1)
+    // (an LDS-DMA instruction costs its wave 30-100 cycles of issue; 16 of them are most of half a step).
+    const int first = steps < 3 ? steps : 3;
+    for (int a = 0; a < first; ++a) issue(a, 0, kLC);
+    if (first == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kLC) : "memory");           // x(0) has landed
     else if (first == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < steps; ++s) {
-      // x(s + 1) has landed = only the tiles behind it (at most x(s + 2), x(s + 3)) may still be on their way
-      const int rem = last - (s + 1);
-      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * kLC) : "memory");
+      const bool more = s + 3 <= last;
+      if (more) issue(s + 3, 0, kLC / 2);
+      // x(s + 1) has landed = only what was requested behind it (x(s + 2) and the half of x(s + 3)) may still be on its way
+      const int rem = last - (s + 1);                             // tiles behind x(s + 1) that exist
+      if (rem >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC + kLC / 2) : "memory");
       else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLC) : "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();                               // a(s)
-      __builtin_amdgcn_s_barrier();                               // b(s): stage s % 4 is free
-      if (s + kT4XStages <= last) issue(s + kT4XStages);
+      if (more) issue(s + 3, kLC / 2, kLC);
+      __builtin_amdgcn_s_barrier();                               // b(s)
     }
     return;
   }
