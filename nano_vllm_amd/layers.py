@@ -583,11 +583,13 @@ class ParallelLMHead(VocabParallelEmbedding):
         self.weight_packed: torch.Tensor | None = None
 
     def pack_for_decode(self, budget_bytes: float = float("inf")) -> int:
-        """Tile-packed copy of the vocabulary matrix for the decode step's lm_head GEMM on deep hidden sizes
-        (Qwen3-8B / 32B: K >= 2048, where nvl_linear_wide on packed weights beats the library GEMM at <= 144 rows —
-        profiles/r03_gemm_wide_lm_head.json; at K = 1024, Qwen3-0.6B, the library GEMM stays). Returns the extra bytes."""
+        """Tile-packed copy of the vocabulary matrix for the decode step's lm_head GEMM: nvl_linear_wide on packed weights
+        beats the library GEMM at <= 144 rows (Qwen3-8B / 32B, K >= 2048: profiles/r03_gemm_wide_lm_head.json; Qwen3-0.6B,
+        K = 1024, round 6: 87-88 us vs 97 at 131 / 144 rows, profiles/r06_lm_head_06b_wide_vs_library.json — the skinny
+        kernel's plan also covers that shape but re-reads x once per 32 columns, so `_logits` calls the wide kernel
+        directly). Returns the extra bytes."""
         n, k = self.weight.shape
-        if (not self.weight.is_cuda or n % 16 or k % 128 or k < 2048 or os.environ.get("NVL_PACKED_WEIGHTS", "1") == "0"
+        if (not self.weight.is_cuda or n % 16 or k % 128 or k < 1024 or os.environ.get("NVL_PACKED_WEIGHTS", "1") == "0"
                 or os.environ.get("NVL_GEMM_WIDE", "auto") == "0" or os.environ.get("NVL_PACKED_LM_HEAD", "1") == "0"
                 or ops.linear_wide_plan(144, n, k, ops.LINEAR_BF16) is None):
             return 0
@@ -598,9 +600,9 @@ class ParallelLMHead(VocabParallelEmbedding):
 
     def _logits(self, x: torch.Tensor) -> torch.Tensor:
         if self.weight_packed is not None and _decode_sized(x) and x.shape[0] <= 144:
-            y = decode_linear(x, self.weight, ops.LINEAR_BF16, packed=self.weight_packed)
-            if y is not None:
-                return y
+            plan = ops.linear_wide_plan(x.shape[0], self.weight.shape[0], x.shape[1], ops.LINEAR_BF16)
+            if plan is not None:
+                return ops.linear_wide(x, self.weight_packed, ops.LINEAR_BF16, workspace=_scratch(plan[1], x.device), packed=True)
         return F.linear(x, self.weight)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor | None:

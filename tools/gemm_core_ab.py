@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SHAPES = {"8b_qkv": (6144, 4096, 0), "8b_o": (4096, 4096, 2), "8b_gate_up": (24576, 4096, 1), "8b_down": (4096, 12288, 2),
           "32b_qkv": (10240, 5120, 0), "32b_o": (5120, 8192, 2), "32b_gate_up": (51200, 5120, 1), "32b_down": (5120, 25600, 2),
-          "14b_gate_up": (34816, 5120, 1), "32b_tp4_gate_up": (12800, 5120, 1), "32b_tp8_gate_up": (6400, 5120, 1)}
+          "14b_gate_up": (34816, 5120, 1), "06b_lm_head": (151936, 1024, 0), "32b_tp4_gate_up": (12800, 5120, 1), "32b_tp8_gate_up": (6400, 5120, 1)}
 
 
 def child(ms):
