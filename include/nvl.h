@@ -252,8 +252,14 @@ int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
 size_t nvl_decode_plan_bytes(void);
 int nvl_decode_plan(const int32_t* context_lens, int64_t batch,
                     int num_q_heads, int num_kv_heads, int64_t max_context,
-                    const int32_t* shared_prefix, int block_size,
+                    const int32_t* shared_prefix, int block_size, int shared_prefix_groups,
                     void* plan, size_t plan_bytes, void* stream);
+/* shared_prefix_groups (ABI 6; read only when shared_prefix != NULL): the member flags are GROUP ids — rows with the
+ * same id > 0 (< 32) start with the same leading blocks, rows of different ids with different ones (two system prompts
+ * in one batch); [0] is the block count EVERY group shares at least (the pass covers that many blocks of each). The
+ * value is the number of different groups ONE pack of floor(16 / (Hq/Hkv)) consecutive rows may hold: the pass's grid
+ * has that many slots per pack (1 = a single group per step, flags 0 / 1: the ABI 5 behaviour; a pack holding more
+ * groups than slots leaves the surplus groups' prefix to... nobody: size it for the worst pack, <= 8). */
 
 /* Decode-step fusion of the three reference launches that precede the attention
  * call on a decode step — q/k RMSNorm (models/qwen3.py:82-84), rotary embedding

@@ -1110,13 +1110,30 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
   const int hq = hkv * Gv;
   const int pack = blockIdx.x / hkv, h = blockIdx.x - pack * hkv;
   const int b0 = pack * P;
-  // the block-table row the prefix tiles are looked up in: the pack's first live member (all members agree on them)
-  int tb = -1;
-  for (int j = P - 1; j >= 0; --j) {
+  // Member flags are GROUP ids (round 6): rows with the same id > 0 start with the same `sh` tiles (two system prompts in one
+  // batch = two groups). A pack is served once per group that has a live member in it — one workgroup (blockIdx.y) per group,
+  // that group's tiles with the other rows as zero columns; almost every pack holds one group. `present`: bit g = group g has
+  // a live member here.
+  unsigned present = 0;
+  for (int j = 0; j < P; ++j) {
     const int bj = b0 + j;
-    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0 && __builtin_amdgcn_readfirstlane(member[bj]) != 0) tb = bj;
+    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0) {
+      const int gm = __builtin_amdgcn_readfirstlane(member[bj]);
+      if (gm > 0 && gm < 32) present |= 1u << gm;
+    }
   }
-  if (tb < 0) return;                                                       // a pack of graph padding / of non-members
+  // blockIdx.y = which of the pack's groups this workgroup serves (the launch has as many y slots as the plan was built for:
+  // 1 unless the engine found several groups); fewer groups in the pack than slots: nothing to do
+  int gid = 0;
+  {
+    unsigned rest = present;
+    for (int sidx = 0; rest != 0; ++sidx) {
+      const int low = __builtin_ctz(rest);
+      if (sidx == (int)blockIdx.y) { gid = low; break; }
+      rest &= rest - 1;
+    }
+  }
+  if (gid == 0) return;                                                     // a pack of graph padding / of non-members
   unsigned char* k_lds = smem_raw + wave * kMWaveLds;
   unsigned char* v_lds = k_lds + kTile * kMKRow;
   int kfrag[4];
@@ -1126,6 +1143,12 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
 
   constexpr int kTL = KV8 ? kLoads8 : kLoads;
   u32x4_t kd[kTL], vd[kTL];
+  // the block-table row the prefix tiles are looked up in: the pack's first live member of this group (all of them agree)
+  int tb = -1;
+  for (int j = P - 1; j >= 0; --j) {
+    const int bj = b0 + j;
+    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0 && __builtin_amdgcn_readfirstlane(member[bj]) == gid) tb = bj;
+  }
   auto tile_block = [&](int ti) { return block_tables[(int64_t)tb * bt_stride + (ti * kTile) / block_size]; };
   auto tile_load = [&](int blk, int ti) {
     const int t = ti * kTile;
@@ -1166,7 +1189,7 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
       const int seq = b0 + r / Gv, hd = r % Gv;
       const int seq_c = seq < batch ? seq : batch - 1;
       const int len = ctx[seq_c];
-      const bool live = r < P * Gv && seq < batch && len > 0 && member[seq_c] != 0;
+      const bool live = r < P * Gv && seq < batch && len > 0 && member[seq_c] == gid;
       u32x4_t qh;
       if constexpr (FUSED) {
         int64_t pos = len > 0 ? len - 1 : 0;
@@ -1301,7 +1324,7 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
       for (int r = 0; r < 4; ++r) oacc[db][r] = oacc[db][r] * fa_ + other[(db * 4 + r) * 64 + lane] * fb_;
   }
   const int seq = b0 + col / Gv, hd = col % Gv;
-  if (col < P * Gv && seq < batch && ctx[seq] > 0 && member[seq] != 0) {
+  if (col < P * Gv && seq < batch && ctx[seq] > 0 && member[seq] == gid) {
     const int64_t pidx = ((int64_t)seq * hq + h * Gv + hd) * slots + (slots - 1);
     float* dst = part_o + pidx * 128 + 4 * quad;
 #pragma unroll
@@ -1425,12 +1448,12 @@ inline int64_t mfma8_grid(int64_t batch, int hkv, int64_t max_context, bool plan
   return grid < 1 ? 1 : grid;
 }
 
-bool plan_shadow_prefix(const void* plan);      // was `plan` built with a shared prefix? (host-side shadow, below)
+int plan_shadow_prefix(const void* plan);       // group slots of the shared-prefix pass `plan` was built with (0: none; host-side shadow, below)
 
 template <bool FUSED, bool KV8, int G, bool SLABS>
 int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                           void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
-                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, bool prefix,
+                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, int prefix,
                           int g_rt);
 
 // qkv as fp32 split-K slabs (fa.qkv_splits > 0) is an instantiation of its own: the bf16 form keeps its registers
@@ -1438,7 +1461,7 @@ template <bool FUSED, bool KV8, int G = 8>
 int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                         void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
                         void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, int g_rt = 0) {
-  const bool prefix = plan != nullptr && plan_shadow_prefix(plan);       // the plan was built with a shared prefix
+  const int prefix = plan != nullptr ? plan_shadow_prefix(plan) : 0;     // group slots of the plan's shared-prefix pass (0: none)
   if constexpr (FUSED) {
     if (fa.qkv_splits > 0)
       return launch_decode_mfma8_s<FUSED, KV8, G, true>(q, kc, vc, bt, bt_stride, ctx, out, batch, hkv, block_size, max_context,
@@ -1451,7 +1474,7 @@ int launch_decode_mfma8(const void* q, void* kc, void* vc, const int32_t* bt, in
 template <bool FUSED, bool KV8, int G, bool SLABS>
 int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, int64_t bt_stride, const int32_t* ctx,
                           void* out, int64_t batch, int hkv, int block_size, int64_t max_context, float scale,
-                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, bool prefix,
+                          void* workspace, hipStream_t s, const FusedArgs& fa, const void* plan, float* lse, int prefix,
                           int g_rt) {
   const int Gv = G > 0 ? G : g_rt;
   const int hq = hkv * Gv;
@@ -1486,7 +1509,7 @@ int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, 
     // relative to the stream-K kernel — which appends the new token's K / V behind the prefix — does not matter)
     const int P = 16 / Gv;
     const int64_t pgrid = ((batch + P - 1) / P) * hkv;
-    hipLaunchKernelGGL((decode_prefix_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)pgrid), dim3(256), kWaves * kMWaveLds, s,
+    hipLaunchKernelGGL((decode_prefix_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)pgrid, (unsigned)prefix), dim3(256), kWaves * kMWaveLds, s,
                        (const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, (int)batch,
                        hkv, block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt);
   }
@@ -1590,12 +1613,12 @@ bool use_valu_g8() {
 // Host-side shadow of the plans nvl_decode_plan has enqueued (keyed by the plan buffer's address): the attention entry
 // points compare the geometry a plan was built for with the launch they are about to make — a plan is a list of
 // per-wave records for ONE (batch, Hkv, max_context, device) and the kernel indexes it by wave id.
-struct PlanShadow { const void* plan; int64_t batch, max_context; int hkv, dev; bool prefix; };
+struct PlanShadow { const void* plan; int64_t batch, max_context; int hkv, dev; int prefix; };
 static PlanShadow g_plan_shadow[64];
 static int g_plan_shadow_n = 0, g_plan_shadow_next = 0;
 static std::mutex g_plan_shadow_mu;
 
-static void plan_shadow_put(const void* plan, int64_t batch, int hkv, int64_t max_context, bool prefix) {
+static void plan_shadow_put(const void* plan, int64_t batch, int hkv, int64_t max_context, int prefix) {
   std::lock_guard<std::mutex> lock(g_plan_shadow_mu);
   const PlanShadow rec = {plan, batch, max_context, hkv, nvl_device_slot(), prefix};
   for (int i = 0; i < g_plan_shadow_n; ++i)
@@ -1605,12 +1628,12 @@ static void plan_shadow_put(const void* plan, int64_t batch, int hkv, int64_t ma
   g_plan_shadow_next = (g_plan_shadow_next + 1) % 64;
 }
 
-bool plan_shadow_prefix(const void* plan) {
+int plan_shadow_prefix(const void* plan) {
   std::lock_guard<std::mutex> lock(g_plan_shadow_mu);
   const int dev = nvl_device_slot();
   for (int i = 0; i < g_plan_shadow_n; ++i)
     if (g_plan_shadow[i].plan == plan && g_plan_shadow[i].dev == dev) return g_plan_shadow[i].prefix;
-  return false;
+  return 0;
 }
 
 static int plan_shadow_check(const void* plan, int64_t batch, int hkv, int64_t max_context, const char* who) {
@@ -1819,14 +1842,16 @@ extern "C" size_t nvl_decode_plan_bytes(void) {
 }
 
 extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int num_q_heads, int num_kv_heads,
-                               int64_t max_context, const int32_t* shared_prefix, int block_size, void* plan,
-                               size_t plan_bytes, void* stream) {
+                               int64_t max_context, const int32_t* shared_prefix, int block_size, int shared_prefix_groups,
+                               void* plan, size_t plan_bytes, void* stream) {
   const int32_t* shared_prefix_blocks = shared_prefix;       // [0] = blocks, [1 + b] = member flags (include/nvl.h)
   const char* who = "nvl_decode_plan";
   NVL_REQUIRE(context_lens && plan, "%s: null pointer", who);
   if (shared_prefix_blocks != nullptr) {
     const int G = num_kv_heads > 0 ? num_q_heads / num_kv_heads : 0;
     NVL_REQUIRE((uintptr_t)shared_prefix_blocks % 4 == 0, "%s: shared_prefix must be 4-byte aligned", who);
+    NVL_REQUIRE(shared_prefix_groups >= 1 && shared_prefix_groups <= 8, "%s: shared_prefix_groups=%d out of range [1, 8]", who,
+                shared_prefix_groups);
     NVL_REQUIRE(block_size > 0 && block_size % 128 == 0, "%s: a shared prefix needs block_size %% 128 == 0 (got %d)", who, block_size);
     NVL_REQUIRE((G == 8 && !use_valu_g8()) || ((G == 2 || G == 4) && use_mfma_small_g()) || (G > 1 && G <= 16 && G != 2 && G != 4 && G != 8),
                 "%s: a shared prefix needs the matrix-core decode kernel (Hq/Hkv in 2 ... 16; got %d)", who, G);
@@ -1853,6 +1878,6 @@ extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int n
                      num_kv_heads, nwaves, (PlanHeader*)plan, shared_prefix_blocks,
                      shared_prefix_blocks ? block_size / kTile : 0);
   const int rc = nvl_check_launch(who);
-  if (rc == NVL_OK) plan_shadow_put(plan, batch, num_kv_heads, max_context, shared_prefix_blocks != nullptr);   // (a failed launch leaves no record)
+  if (rc == NVL_OK) plan_shadow_put(plan, batch, num_kv_heads, max_context, shared_prefix_blocks != nullptr ? shared_prefix_groups : 0);   // (a failed launch leaves no record)
   return rc;
 }

@@ -153,14 +153,19 @@ def _align(n: int, a: int = 16) -> int:
     return (n + a - 1) // a * a
 
 
-def shared_prefix_group(bt: np.ndarray, lens: np.ndarray, block_size: int):
-    """(k, member): the rows of a decode batch that start with the same KV blocks, and how many. The group is the set of
-    rows whose FIRST block id is the most frequent one; k = the number of leading columns of bt on which all of them
-    agree — what the prefix cache hands out when requests start with the same tokens (block_manager.py:58-82: a cache
-    hit appends the block id of the request that registered it; requests prefilled in the step that first computed the
-    prefix hold private copies, :110-120, and are not members). Only blocks that lie completely before the newest token
-    of the shortest member count (k <= (min(len) - 1) // block_size): the block a member is still writing is never
-    shared. (0, None): nothing to share."""
+MAX_PREFIX_GROUPS = 4          # shared prefixes one decode step shares at most (group slots per pack of the attention pass)
+
+
+def shared_prefix_group(bt: np.ndarray, lens: np.ndarray, block_size: int, max_groups: int = MAX_PREFIX_GROUPS):
+    """(k, member): the rows of a decode batch that start with the same KV blocks, and how many. member[row] = 0 (not a
+    member) or a GROUP id 1, 2, ...: rows of one group have the same FIRST block id — what the prefix cache hands out when
+    requests start with the same tokens (block_manager.py:58-82: a cache hit appends the block id of the request that
+    registered it; requests prefilled in the step that first computed the prefix hold private copies, :110-120, and are
+    not members). Group 1 is the largest group and sets k = the number of leading columns of bt on which all its rows
+    agree; every further group of >= 2 rows (largest first, `max_groups` in all: two system prompts in one batch) joins
+    if its rows agree on their first k columns as well — the attention pass then covers k blocks of EVERY group. Only
+    blocks that lie completely before the newest token of the shortest member count (k <= (min(len) - 1) // block_size):
+    the block a member is still writing is never shared. (0, None): nothing to share."""
     n = len(lens)
     if n < 2:
         return 0, None
@@ -168,17 +173,32 @@ def shared_prefix_group(bt: np.ndarray, lens: np.ndarray, block_size: int):
     vals, counts = np.unique(first, return_counts=True)
     if len(vals) == n:                                          # (the common case: all different)
         return 0, None
-    j = int(counts.argmax())
+    order = np.argsort(-counts, kind="stable")
+    j = int(order[0])
     if counts[j] < 2 or vals[j] < 0:
         return 0, None
-    member = first == vals[j]
-    rows = np.nonzero(member)[0]
+    rows = np.nonzero(first == vals[j])[0]
     cap = min(int((int(lens[rows].min()) - 1) // block_size), bt.shape[1])
     if cap <= 0:
         return 0, None
     same = (bt[rows, :cap] == bt[rows[0], :cap]).all(axis=0)
     k = cap if same.all() else int(np.argmin(same))
-    return (k, member) if k > 0 else (0, None)
+    if k <= 0:
+        return 0, None
+    member = np.zeros(n, dtype=np.int32)
+    member[rows] = 1
+    gid = 1
+    for j in order[1:]:
+        if gid >= max_groups or counts[j] < 2:
+            break
+        if vals[j] < 0:
+            continue
+        rows = np.nonzero(first == vals[j])[0]
+        if (int(lens[rows].min()) - 1) // block_size < k or not (bt[rows, :k] == bt[rows[0], :k]).all():
+            continue                                            # shorter than, or not agreeing on, the k blocks the pass covers
+        gid += 1
+        member[rows] = gid
+    return k, member
 
 
 class _Stage:
@@ -471,8 +491,9 @@ class ModelRunner:
                                                                       self.block_size))
         self.share_prefix_min_bytes = float(os.environ.get("NVL_SHARED_PREFIX_MIN_MB", "160")) * 1e6
         self.decode_plan_px = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
-        self.graphs_px: dict[int, torch.cuda.CUDAGraph] = {}
+        self.graphs_px: dict[tuple, torch.cuda.CUDAGraph] = {}      # (bucket, group slots) -> graph with the pass
         self.prefix_steps = 0                # decode steps that ran the shared-prefix pass (reporting)
+        self.prefix_multi_steps = 0          # ... with more than one shared prefix in the batch
         self._step_done = [torch.cuda.Event(), torch.cuda.Event()]
         # TP with the xGMI P2P collectives: every spin of those kernels is bounded, and a timeout is LATCHED in the shared
         # flag region while the step carries on with an invalid sum. The last node of every step (prefill and decode,
@@ -620,7 +641,7 @@ class ModelRunner:
         k, member = self._prefix_group_worth_a_pass(bt, lens, n) if (self.share_prefix and self._seen_cached_kv) else (0, None)
         st["shp"][0] = k
         if k > 0:
-            st["shp"][1:1 + n] = member
+            st["shp"][1:1 + n] = member                     # group ids (0: not a member)
         # neutralise rows used by a previous, larger batch (graph padding: slot -1, context 0)
         dirty = self._dirty[self.dstage.cur]
         if dirty > n:
@@ -638,10 +659,11 @@ class ModelRunner:
             return 0, None
         pack = 16 // (self.geo["heads"] // self.geo["kv_heads"])
         esize = 1 if self.config.kv_cache_dtype == "fp8" else 2
-        m = int(member.sum())
-        # the pass reads the prefix once per pack of CONSECUTIVE rows that holds a member (non-members ride along as zero
-        # columns): members scattered among non-members share less than m / pack packs
-        npacks = len(np.unique(np.nonzero(member)[0] // pack))
+        m = int((member > 0).sum())
+        # the pass reads a group's prefix once per pack of CONSECUTIVE rows that holds a member of it (the other rows ride
+        # along as zero columns): members scattered among other rows share less than m / pack packs
+        idx = np.nonzero(member)[0]
+        npacks = len(np.unique((idx // pack) * (MAX_PREFIX_GROUPS + 1) + member[idx]))
         saved = k * self.block_size * (m - npacks) * self.geo["kv_heads"] * 2 * 128 * esize
         return (k, member) if saved >= self.share_prefix_min_bytes else (0, None)
 
@@ -663,14 +685,16 @@ class ModelRunner:
             logits = self.model.compute_logits_shard(hidden)
             sampler.forward_shard(logits, temps, col0, out, offset_dev=rng, row_keys=rkey)
 
-    def _decode_rows(self, r0: int, r1: int, ws, sampler, plan=None, prefix: bool = False):
-        """Decode forward for rows [r0, r1) of the static device buffers, on the current stream. `prefix`: the plan
-        carries the step's shared-prefix group (staged as `shp`), the attention launches run the shared pass."""
+    def _decode_rows(self, r0: int, r1: int, ws, sampler, plan=None, prefix: int = 0):
+        """Decode forward for rows [r0, r1) of the static device buffers, on the current stream. `prefix` > 0: the plan
+        carries the step's shared-prefix groups (staged as `shp`), the attention launches run the shared pass with that
+        many group slots per pack (1: one shared prefix in the step; MAX_PREFIX_GROUPS: several)."""
         t = self.dstage.t
         assert not prefix or r0 == 0           # (the member flags are staged per row of the whole batch)
         if plan is not None:
             ops.decode_plan(t["ctx"][r0:r1], self.geo["heads"], self.geo["kv_heads"], self.config.max_model_len, plan,
-                            shared_prefix=t["shp"] if prefix else None, block_size=self.block_size)
+                            shared_prefix=t["shp"] if prefix else None, block_size=self.block_size,
+                            prefix_groups=max(prefix, 1))
         set_context(False, slot_mapping=t["slots"][r0:r1], context_lens=t["ctx"][r0:r1],
                     block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len,
                     decode_plan=plan)
@@ -692,7 +716,7 @@ class ModelRunner:
                                "collectives over the process group instead")
 
     @torch.inference_mode()
-    def _forward_decode(self, bs: int, prefix: bool = False):
+    def _forward_decode(self, bs: int, prefix: int = 0):
         """Decode forward on the static device buffers (captured per bucket, or run eagerly): layers + lm_head
         + sampler, at any TP degree (the reference captures the layers only and runs lm_head, the logits
         gather and the sampler eagerly, model_runner.py:212,218). (A micro-batched form — two half-batch chains on
@@ -709,15 +733,21 @@ class ModelRunner:
         """Every rank: upload the current image, run the step, start the D2H of the ids (rank 0)."""
         self.dstage.upload()
         bucket = next((b for b in self.graph_bs if b >= n), None) if self.graphs else None
-        prefix = self.share_prefix and int(self.dstage.np["shp"][0]) > 0       # (every rank reads the same image)
-        self.prefix_steps += int(prefix)
-        if bucket is not None and prefix and bucket not in self.graphs_px and not self._capture_prefix_graph(bucket):
+        # (every rank reads the same image: the group count is the largest group id among the staged flags)
+        prefix = 0
+        if self.share_prefix and int(self.dstage.np["shp"][0]) > 0:
+            prefix = 1 if int(self.dstage.np["shp"][1:1 + n].max()) <= 1 else MAX_PREFIX_GROUPS
+        self.prefix_steps += int(prefix > 0)
+        self.prefix_multi_steps += int(prefix > 1)
+        key = (bucket, prefix)
+        if bucket is not None and prefix and key not in self.graphs_px and not self._capture_prefix_graph(bucket, prefix):
             # the capture failed (single rank only; _capture_prefix_graph raises under TP): this step replays the bucket's
-            # plain graph, whose plan is built without the staged group
-            prefix = False
+            # plain graph, whose plan is built without the staged groups
             self.prefix_steps -= 1
+            self.prefix_multi_steps -= int(prefix > 1)
+            prefix = 0
         if bucket is not None and prefix:
-            self.graphs_px[bucket].replay()
+            self.graphs_px[key].replay()
         elif bucket is not None:
             self.graphs[bucket].replay()
         else:
@@ -825,15 +855,15 @@ class ModelRunner:
             # what a prefix graph needs before the serving path asks for one; the other buckets' prefix graphs are captured
             # when a step first wants them (most workloads never do). The kernels' LDS reservations are made by the launcher
             # of the plain kernel (attn_decode.hip), i.e. during the eager warm-ups above, never inside a capture.
-            self._forward_decode(self.graph_bs[-1], prefix=True)
+            self._forward_decode(self.graph_bs[-1], prefix=1)
             torch.cuda.synchronize()
-            self._capture_prefix_graph(self.graph_bs[-1])
+            self._capture_prefix_graph(self.graph_bs[-1], 1)
         torch.cuda.synchronize()
         from .. import layers
         layers.release_tuning_scratch()                 # the decode-GEMM choices of every bucket are made by now
 
     @torch.inference_mode()
-    def _capture_prefix_graph(self, bs: int) -> bool:
+    def _capture_prefix_graph(self, bs: int, groups: int = 1) -> bool:
         """The decode graph of bucket `bs` WITH the shared-prefix attention pass, captured the first time a step wants
         it (most workloads never do; the largest bucket's is captured at start-up). No warm-up run on the serving path:
         the static buffers hold a real step's inputs by now, every choice the launches make was made when the bucket's
@@ -845,7 +875,7 @@ class ModelRunner:
         graph = torch.cuda.CUDAGraph()
         try:
             with torch.cuda.graph(graph, self.graph_pool):
-                self._forward_decode(bs, prefix=True)
+                self._forward_decode(bs, prefix=groups)
         except Exception as e:      # OOM of the pool's headroom, a launch refused inside the capture
             if self.world_size > 1:
                 raise
@@ -853,5 +883,5 @@ class ModelRunner:
             warnings.warn(f"shared-prefix graph of bucket {bs} could not be captured ({e!r}); the pass is off")
             self.share_prefix = False
             return False
-        self.graphs_px[bs] = graph
+        self.graphs_px[(bs, groups)] = graph
         return True

@@ -45,7 +45,7 @@ SIGNATURES = {
                                       c_int, c_int, c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int,
                                       c_void_p, c_void_p, c_void_p]),
     "nvl_decode_plan_bytes": (c_size_t, []),
-    "nvl_decode_plan": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_int, c_void_p, c_size_t, c_void_p]),
+    "nvl_decode_plan": (c_int, [c_void_p, c_int64, c_int, c_int, c_int64, c_void_p, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "nvl_paged_attn_decode_fused": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p, c_int64, c_void_p,
                                             c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int,
                                             c_int, c_int64, c_int64, c_float, c_void_p, c_size_t, c_int, c_void_p,
@@ -339,12 +339,13 @@ def decode_plan_bytes() -> int:
 
 def decode_plan(context_lens: torch.Tensor, num_q_heads: int, num_kv_heads: int, max_context: int,
                 plan: torch.Tensor | None = None, shared_prefix: torch.Tensor | None = None,
-                block_size: int = 256) -> torch.Tensor:
+                block_size: int = 256, prefix_groups: int = 1) -> torch.Tensor:
     """Per-step work plan of the decode attention launches (same for every layer of the step): `plan` is a uint8
     device buffer of decode_plan_bytes() bytes, allocated when None. `shared_prefix`: int32 device tensor [1 + batch] —
     [0] = number of leading KV blocks the member sequences have in common, [1 + b] != 0 marks sequence b as a member;
     the attention calls that consume this plan then run the shared-prefix pass, and read the member flags from this
-    tensor's memory when they run (include/nvl.h)."""
+    tensor's memory when they run (include/nvl.h). `prefix_groups` > 1: the flags are group ids (several shared prefixes in one
+    step) and a pack of rows may hold up to that many different groups."""
     _dev(context_lens, "context_lens")
     assert context_lens.dtype == torch.int32 and context_lens.is_contiguous()
     if plan is None:
@@ -355,7 +356,7 @@ def decode_plan(context_lens: torch.Tensor, num_q_heads: int, num_kv_heads: int,
         assert shared_prefix.is_contiguous() and shared_prefix.numel() >= 1 + context_lens.numel()
         shp = shared_prefix.data_ptr()
     _check(lib().nvl_decode_plan(context_lens.data_ptr(), context_lens.numel(), num_q_heads, num_kv_heads, max_context,
-                                 shp, block_size, plan.data_ptr(), plan.numel(), _stream()))
+                                 shp, block_size, prefix_groups, plan.data_ptr(), plan.numel(), _stream()))
     return plan
 
 

@@ -70,13 +70,15 @@ def test_host_side_argument_validation_without_gpu():
                                          4096, 0.1, 16, 1 << 30, 0, None, None, 2, 1 << 20, None)
     assert rc == -3 and b"matrix-core" in lib.nvl_last_error()          # Hq / Hkv = 1: the packed-dot kernel
     # per-step decode plan: buffer size is validated on the host
-    rc = lib.nvl_decode_plan(16, 4, 16, 8, 4096, None, 0, 16, 8, None)
+    rc = lib.nvl_decode_plan(16, 4, 16, 8, 4096, None, 0, 1, 16, 8, None)
     assert rc == -1 and b"plan buffer" in lib.nvl_last_error()
     # ... with a shared-prefix count (ABI v5): block size and head geometry are checked before anything is launched
-    rc = lib.nvl_decode_plan(16, 4, 16, 8, 4096, 16, 96, 16, 1 << 20, None)
+    rc = lib.nvl_decode_plan(16, 4, 16, 8, 4096, 16, 96, 1, 16, 1 << 20, None)
     assert rc == -1 and b"block_size % 128" in lib.nvl_last_error()
-    rc = lib.nvl_decode_plan(16, 4, 8, 8, 4096, 16, 256, 16, 1 << 20, None)
+    rc = lib.nvl_decode_plan(16, 4, 8, 8, 4096, 16, 256, 1, 16, 1 << 20, None)
     assert rc == -1 and b"matrix-core" in lib.nvl_last_error()
+    rc = lib.nvl_decode_plan(16, 4, 16, 8, 4096, 16, 256, 9, 16, 1 << 20, None)      # (ABI v6: group slots of the pass)
+    assert rc == -1 and b"shared_prefix_groups" in lib.nvl_last_error()
     # skinny linear: shape coverage is a query, an uncovered shape is EUNSUPPORTED (-3), never a silent fallback
     assert lib.nvl_linear_decode_splits(144, 4096, 1024, 0) == 1
     assert lib.nvl_linear_decode_splits(144, 1024, 2048, 2) == 2      # (three row groups x a 2-way K split from 9 row tiles on)

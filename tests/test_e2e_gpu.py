@@ -59,7 +59,8 @@ def _run_ours(path, prompts, max_tokens, capture_logits=False, temperatures=None
     nblk = llm.config.num_kvcache_blocks
     runner.call = orig
     if info is not None:
-        info.update(prefix_steps=runner.prefix_steps, prefix_graphs=sorted(runner.graphs_px))
+        info.update(prefix_steps=runner.prefix_steps, prefix_graphs=sorted(runner.graphs_px),
+                    prefix_multi_steps=runner.prefix_multi_steps)
     llm.exit()
     if capture_logits:
         assert len(logits_log) == len(rec)
@@ -708,9 +709,9 @@ def test_kvcache_block_size_512_with_a_shared_system_prompt(eager, monkeypatch):
 
 def test_two_shared_system_prompts_in_one_batch(monkeypatch):
     """Two groups of requests, each with its own 530-token system prompt, decode in ONE batch. The step's shared-prefix
-    pass takes the LARGEST group (engine/runner.py `shared_prefix_group`); the rows of the other group — which share
-    blocks among themselves, not with the chosen one — must come out of the plain per-sequence kernel exactly as before.
-    Judged against the oracle engine (schedule, block tables, tokens; greedy and sampled rows)."""
+    pass serves BOTH groups (engine/runner.py `shared_prefix_group`: group ids; round 5 shared the largest group only):
+    rows of one group share their two leading blocks among themselves, not with the other group, and a pack of rows may
+    hold members of both. Judged against the oracle engine (schedule, block tables, tokens; greedy and sampled rows)."""
     from nano_vllm_amd.weights import write_synthetic_checkpoint
     monkeypatch.setenv("NVL_SHARED_PREFIX_MIN_MB", "0")
     path = tempfile.mkdtemp(prefix="qwen3_tiny_two_prefixes_")
@@ -733,7 +734,8 @@ def test_two_shared_system_prompts_in_one_batch(monkeypatch):
         heads = [tuple(t[:2]) for t in r["tables"] if len(t) > 2]
         return sorted((heads.count(h) for h in set(heads)), reverse=True)
     assert any(len(c) >= 2 and c[1] >= 2 for c in map(groups, (r for r in rec if not r["prefill"]))), "never two shared groups"
-    assert info["prefix_steps"] > 0, info
+    assert info["prefix_steps"] > 0 and info["prefix_multi_steps"] > 0, info
+    assert any(k[1] > 1 for k in info["prefix_graphs"]), info           # a graph with several group slots was captured
     _check("two shared system prompts in one batch",
            _judge(path, prompts, max_tokens, rec, nblk, temperatures=temps, seed=8, max_num_seqs=16,
                   max_num_batched_tokens=1280), sum(max_tokens))

@@ -220,7 +220,7 @@ def test_shared_prefix_group_helper_and_the_launch_threshold():
     bt[5, :4] = [20, 21, 22, 23]                 # a private copy of the same content: not a member
     lens = np.array([900, 800, 1000, 770, 1024, 1000])
     k, mem = shared_prefix_group(bt, lens, 256)
-    assert k == 3 and mem.tolist() == [True] * 5 + [False]
+    assert k == 3 and mem.tolist() == [1] * 5 + [0]
     assert shared_prefix_group(bt, np.array([900, 800, 1000, 769, 1024, 1000]), 256)[0] == 3      # (769 - 1) // 256 = 3
     assert shared_prefix_group(bt, np.array([900, 800, 1000, 768, 1024, 1000]), 256)[0] == 2      # block 2 holds that row's newest token
     assert shared_prefix_group(bt, np.array([900, 800, 1000, 770, 1024, 10]), 256)[0] == 3        # a short NON-member does not clamp
@@ -231,6 +231,22 @@ def test_shared_prefix_group_helper_and_the_launch_threshold():
     bt2[:, 0] = np.arange(6)
     assert shared_prefix_group(bt2, lens, 256) == (0, None)             # all first blocks differ
     assert shared_prefix_group(np.full((4, 8), -1, dtype=np.int32), np.array([300] * 4), 256) == (0, None)   # empty tables
+    # SEVERAL groups (two system prompts in one batch): the largest group is group 1 and sets k; a further group joins with
+    # the next id when its rows agree on THEIR first k blocks and are long enough; a third one that is too short, one that
+    # disagrees inside the k blocks, and single rows stay plain
+    bt3 = np.full((12, 8), -1, dtype=np.int32)
+    bt3[0:5, :3] = [7, 9, 4]                      # group A: 5 rows, 3 common blocks
+    bt3[5:8, :3] = [30, 31, 32]                   # group B: 3 rows, 3 common blocks
+    bt3[8:10, :3] = [40, 41, 42]                  # group C: 2 rows, too short for 3 blocks
+    bt3[10, :3] = [50, 51, 52]                    # a single row
+    bt3[11, :3] = [30, 99, 32]                    # starts like group B but disagrees on block 1: breaks B's agreement
+    lens3 = np.array([900, 800, 1000, 770, 1024, 800, 801, 900, 600, 601, 900, 900])
+    k3, mem3 = shared_prefix_group(bt3[:11], lens3[:11], 256)
+    assert k3 == 3 and mem3.tolist() == [1] * 5 + [2] * 3 + [0, 0] + [0]
+    k3, mem3 = shared_prefix_group(bt3, lens3, 256)
+    assert k3 == 3 and mem3.tolist() == [1] * 5 + [0] * 7          # B's rows no longer agree on their first 3 blocks
+    k3, mem3 = shared_prefix_group(bt3[:11], lens3[:11], 256, max_groups=1)
+    assert mem3.tolist() == [1] * 5 + [0] * 6
     # the threshold: K/V bytes saved per layer = blocks x 256 tokens x (members - packs) x Hkv x 2 x 128 x 2 B
     eng = _engine(True, max_num_seqs=8, max_model_len=2048, num_kvcache_blocks=40)
     run = eng.model_runner                       # geometry: 4 query heads, 2 kv heads => packs of 8 rows

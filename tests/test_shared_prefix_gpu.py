@@ -1,4 +1,4 @@
-"""Shared-prefix pass of the decode attention (nvl_decode_plan's `shared_prefix`, ABI v5) against the plain
+"""Shared-prefix pass of the decode attention (nvl_decode_plan's `shared_prefix`, ABI v5; group ids: v6) against the plain
 launch and against the CPU oracle.
 
 The reference's prefix cache (engine/block_manager.py:58-82) gives every request that starts with the same tokens the
@@ -205,6 +205,64 @@ def test_unfused_decode_clamps_the_shared_prefix_to_the_shortest_row(ops, hq, hk
         for i, n in enumerate(lens):
             if n == 0:
                 assert not o1[i].any()
+
+
+@pytest.mark.parametrize("hq,hkv", [(16, 8), (32, 8), (8, 1), (40, 8)])
+@pytest.mark.parametrize("slots", [2, 4])
+def test_several_shared_prefixes_in_one_step(ops, hq, hkv, slots):
+    """Two (three) system prompts in one batch (ABI 6: the member flags are group ids, `prefix_groups` = group slots per
+    pack): rows of group 1 share two blocks among themselves, rows of group 2 two OTHER blocks, rows of group 3 a third
+    pair; groups are interleaved in row order, so packs hold one, two or three groups, plus non-members and padding rows.
+    Every row must match the oracle on ITS OWN block table (output and LSE), and the launch must differ from the plain one
+    on the rows of every group (each group's prefix really went through the pass). With one slot only (the ABI 5 form)
+    the same flags serve the lowest group id of a pack and nothing else of that pack — which this test shows is NOT
+    enough for mixed packs (outputs of surplus groups' rows are then wrong): sizing the slots is the caller's job."""
+    gen = g(340 + slots)
+    groups = [1, 2, 1, 0, 2, 1, 3, 2, 0, 1, 3, 2, 1, 0, 0, 2, 3, 1, 2, 1, 1, 2, 0, 3]          # 0 = shares nothing
+    lens = [513 + 41 * i for i in range(len(groups))]
+    lens[8], lens[14] = 0, 0                                                                    # padding rows
+    b = len(lens)
+    nb = [(n + BS - 1) // BS for n in lens]
+    total = 6 + sum(nb) + 3
+    perm = torch.randperm(total, generator=gen).tolist()
+    common = {1: perm[0:2], 2: perm[2:4], 3: perm[4:6]}
+    rest = iter(perm[6:])
+    bt = torch.full((b, MAX_CTX // BS), -1, dtype=torch.int32)
+    for i, n in enumerate(nb):
+        for j in range(n):
+            bt[i, j] = common[groups[i]][j] if (groups[i] and j < 2) else next(rest)
+    kc = torch.randn(total, BS, hkv, 128, generator=gen).to(BF16)           # token-major (the oracle's layout)
+    vc = torch.randn(total, BS, hkv, 128, generator=gen).to(BF16)
+    q = torch.randn(b, hq, 128, generator=gen).to(BF16)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    scale = 128 ** -0.5
+    o_ref, lse_ref = ref.flash_attn_with_kvcache(q.unsqueeze(1), kc, vc, ctx, bt, scale, return_softmax_lse=True)
+    o_ref = o_ref.squeeze(1)
+    dq, dk, dv = q.cuda(), ref.to_head_major(kc).cuda(), ref.to_head_major(vc).cuda()
+    dctx, dbt = ctx.cuda(), bt.cuda()
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, MAX_CTX), dtype=torch.uint8, device="cuda")
+    o0 = ops.paged_attn_decode(dq, dk, dv, dbt, dctx, scale, MAX_CTX, ws, plan=ops.decode_plan(dctx, hq, hkv, MAX_CTX))
+    shp = torch.tensor([2] + groups, dtype=torch.int32, device="cuda")
+    plan = ops.decode_plan(dctx, hq, hkv, MAX_CTX, shared_prefix=shp, block_size=BS, prefix_groups=slots)
+    lse1 = torch.zeros(b, hq, dtype=torch.float32, device="cuda")
+    o1 = ops.paged_attn_decode(dq, dk, dv, dbt, dctx, scale, MAX_CTX, torch.zeros_like(ws), plan=plan, lse=lse1)
+    torch.cuda.synchronize()
+    live = [i for i, n in enumerate(lens) if n > 0]
+    pack = 16 // (hq // hkv)
+    worst_pack = max(len({groups[i] for i in range(p0, min(p0 + pack, b)) if groups[i] and lens[i] > 0}) for p0 in range(0, b, pack))
+    err = (o1.cpu().float() - o_ref.float()).abs().amax(dim=(1, 2))
+    tol = 2e-2 * float(o_ref.float().abs().max()) + 1e-3
+    if slots >= worst_pack:
+        assert float(err[live].max()) <= tol
+        assert float((lse1.cpu()[live] - lse_ref[live]).abs().max()) <= 2e-3
+        for gid in (1, 2, 3):
+            rows = [i for i in live if groups[i] == gid]
+            assert not torch.equal(o1[rows], o0[rows]), f"group {gid} did not go through the pass"
+    else:
+        assert float(err[live].max()) > tol           # three groups in a pack, two slots: a group's prefix is missing
+    for i, n in enumerate(lens):
+        if n == 0:
+            assert not o1[i].any()
 
 
 def test_shared_prefix_count_is_read_when_the_captured_plan_replays(ops):

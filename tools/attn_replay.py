@@ -109,7 +109,8 @@ def replay(torch, kv_cache, samples, hq: int, hkv: int, max_ctx: int, ws, reps: 
         q = q_all[:n]
         shared, member = shared_blocks_of(bt, np.asarray(ctx, dtype=np.int64), n) if (plan and shared_blocks_of) else (0, None)
         shp = torch.tensor([shared, *member.astype(np.int32).tolist()], dtype=torch.int32, device=dev) if shared > 0 else None
-        step_plan = ops.decode_plan(ctx_d, hq, hkv, max_ctx, shared_prefix=shp, block_size=block_size) if plan else None
+        groups = 1 if shared == 0 or int(member.max()) <= 1 else 4       # (as the engine: one slot, or MAX_PREFIX_GROUPS)
+        step_plan = ops.decode_plan(ctx_d, hq, hkv, max_ctx, shared_prefix=shp, block_size=block_size, prefix_groups=groups) if plan else None
 
         def layers():
             for layer in range(L):
