@@ -54,16 +54,28 @@ constexpr int kTileBytes = kKBlk * (kKRowB + kVRowB);   // one K + V tile pair i
 // tile requested during the last tile of the current one — was built and measured in round 4: +13 % on equal-length
 // batches, -8 ... -12 % on the bench's ragged ones, a dynamic per-XCD ticket queue slower than both. Retired:
 // tools/probes/rejected/attn_prefill_persistent_walk.hip.txt, profiles/r04_prefill_persist_ab.json.)
-template <bool PAGED, bool KV8, int NW>
+// PP (NW = 8 only): the PING-PONG form of the 8-wave shape. The plain 8-wave loop keeps all eight waves in lockstep
+// (one barrier per tile): the two waves of a SIMD run QK^T together, then the softmax together, then P.V together, so
+// the matrix pipe idles through every softmax and the VALU through every MFMA phase (27-39 % of wave cycles issuing,
+// profiles/r05_prefill_pmc_waits.json). Here the two halves of the workgroup (waves 0-3 = q-head A, waves 4-7 = q-head B:
+// one wave of each per SIMD) run the same per-tile program ONE BARRIER INTERVAL apart, and the program is split into a
+// matrix interval M(t) = {P.V of tile t-1, QK^T of tile t} (32 MFMAs + the K / V fragment reads, no VALU) and a vector
+// interval SM(t) = {online softmax of tile t, LDS write of the staged tile pair, issue of the next pair's loads}: in
+// every interval each SIMD has one wave feeding the matrix pipe and one wave on the VALU (MI355X_MICROARCH.md "Two waves
+// per SIMD"; cdna_hip_programming.md T16). K runs one tile ahead of V in LDS: the pair staged during the intervals
+// (2t, 2t+1) is {K(t+1), V(t)}, into the buffers whose last readers (QK^T(t-1), P.V(t-2)) finished in interval 2t-1.
+template <bool PAGED, bool KV8, int NW, bool PP = false, int VAR = 0>
 __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_tok_stride,
     int64_t v_tok_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, bf16_t* __restrict__ out, int num_seqs, int hq,
-    int hkv, int block_size, float scale_log2e, int xcd_map, float* __restrict__ lse) {
+    int hkv, int block_size, float scale_log2e, int xcd_map, float* __restrict__ lse, float rescale_thr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  // two {K: 64 x 256 B, V: 64 x 320 B} tile buffers, then the tile-lookup scratch
+  // two {K: 64 x 256 B, V: 64 x 320 B} tile buffers, then the tile-lookup scratch (PP: the second buffer starts at
+  // 64 KiB — the loop toggles buffers at run time, and the workgroup owns the CU's LDS anyway)
   constexpr int NT = NW * 64;                            // threads per workgroup
-  int* wsum = reinterpret_cast<int*>(smem + 2 * kTileBytes);
+  constexpr int kBufStride = PP ? 65536 : kTileBytes;
+  int* wsum = reinterpret_cast<int*>(smem + kBufStride + kTileBytes);
   int* pre = wsum + 8;                                  // [num_seqs + 1]
 
   const int tid = threadIdx.x, lane = tid & 63, wave_all = tid >> 6;
@@ -245,70 +257,71 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   // offsets above): no per-tile address VALU, nothing the loads depend on is rewritten while they are in
   // flight, and rows past the end of the sequence / block come back as zeros from the hardware range check
   // (they are masked anyway).
-  // issue the global loads of the tile starting at key kt of the item (sequence seq_, kv-head kvh_, keys k0_ .. k0_ + lk_)
-  auto stage_load_of = [&](int seq_, int kvh_, int k0_, int lk_, int kt) {
-    __amdgpu_buffer_rsrc_t krs, vrs;
-    int ksoff, vsoff;
+  // issue the global loads of the K (IS_K) or V rows of the tile starting at key kt of the item (sequence seq_, kv-head
+  // kvh_, keys k0_ .. k0_ + lk_) into kreg / vreg
+  auto load_rows = [&](auto is_k, int seq_, int kvh_, int k0_, int lk_, int kt) __attribute__((always_inline)) {
+    constexpr bool IS_K = decltype(is_k)::value;
+    const bf16_t* src = IS_K ? k : v;
+    const int64_t tok_stride = IS_K ? k_tok_stride : v_tok_stride, rstride = IS_K ? kstride : vstride;
+    u32x4_t (&reg)[4] = *(IS_K ? &kreg : &vreg);
+    const unsigned int (&roff)[4] = *(IS_K ? &koff : &voff);
+    __amdgpu_buffer_rsrc_t rs;
+    int soff;
     if constexpr (PAGED) {
       const int blk = block_tables[(int64_t)seq_ * bt_stride + kt / block_size];
       const int64_t base = (((int64_t)blk * hkv + kvh_) * block_size + (kt % block_size)) * 128;
-      if constexpr (KV8) {
-        krs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)k + base), 0, kKBlk * 128, 0x00020000);
-        vrs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)v + base), 0, kKBlk * 128, 0x00020000);
-      } else {
-        krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + base), 0, kKBlk * 256, 0x00020000);
-        vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + base), 0, kKBlk * 256, 0x00020000);
-      }
-      ksoff = vsoff = 0;
+      if constexpr (KV8) rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)src + base), 0, kKBlk * 128, 0x00020000);
+      else rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + base), 0, kKBlk * 256, 0x00020000);
+      soff = 0;
     } else {
-      krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)k0_ * k_tok_stride + kvh_ * 128), 0,
-                                              (int)(lk_ * kstride * 2), 0x00020000);
-      vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)k0_ * v_tok_stride + kvh_ * 128), 0,
-                                              (int)(lk_ * vstride * 2), 0x00020000);
-      ksoff = (int)(kt * kstride * 2);
-      vsoff = (int)(kt * vstride * 2);
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (int64_t)k0_ * tok_stride + kvh_ * 128), 0,
+                                             (int)(lk_ * rstride * 2), 0x00020000);
+      soff = (int)(kt * rstride * 2);
     }
     if constexpr (KV8) {
       // 64 keys x 128 B = 512 16-byte chunks (chunk = tid + NT n -> row chunk >> 3, 16 elements)
 #pragma unroll
-      for (int n = 0; n < kCh8; ++n) {
-        kreg[n] = __builtin_amdgcn_raw_buffer_load_b128(krs, (tid + n * NT) * 16, ksoff, 0);
-        vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(vrs, (tid + n * NT) * 16, vsoff, 0);
-      }
+      for (int n = 0; n < kCh8; ++n) reg[n] = __builtin_amdgcn_raw_buffer_load_b128(rs, (tid + n * NT) * 16, soff, 0);
     } else {
 #pragma unroll
-      for (int n = 0; n < kCh; ++n) {
-        kreg[n] = __builtin_amdgcn_raw_buffer_load_b128(krs, koff[n], ksoff, 0);
-        vreg[n] = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff[n], vsoff, 0);
-      }
+      for (int n = 0; n < kCh; ++n) reg[n] = __builtin_amdgcn_raw_buffer_load_b128(rs, roff[n], soff, 0);
     }
   };
+  auto stage_load_of = [&](int seq_, int kvh_, int k0_, int lk_, int kt) {
+    load_rows(std::true_type{}, seq_, kvh_, k0_, lk_, kt);
+    load_rows(std::false_type{}, seq_, kvh_, k0_, lk_, kt);
+  };
   auto stage_load = [&](int kt) { stage_load_of(seq, kvh, k0, lk, kt); };
-  auto stage_write = [&](int buf) {     // registers -> LDS tile buffer `buf`
-    unsigned char* kl = smem + buf * kTileBytes;
-    unsigned char* vl = kl + kKBlk * kKRowB;
+  // registers -> LDS: the K rows (16-byte XOR swizzle) or the V rows (row-major, padded stride) of tile buffer `buf`
+  auto write_rows = [&](auto is_k, int buf) __attribute__((always_inline)) {
+    constexpr bool IS_K = decltype(is_k)::value;
+    unsigned char* dst = smem + buf * kBufStride + (IS_K ? 0 : kKBlk * kKRowB);
+    const u32x4_t (&reg)[4] = *(IS_K ? &kreg : &vreg);
+    constexpr int rowb = IS_K ? kKRowB : kVRowB;
     if constexpr (KV8) {
 #pragma unroll
       for (int n = 0; n < kCh8; ++n) {
         const int chunk = tid + n * NT;
         const int row = chunk >> 3, c16 = (chunk & 7) * 2;          // two bf16 16-byte chunks per fp8 chunk
+        const int sw = IS_K ? (row & 15) : 0;
         u32x4_t a, b;
-        fp8x16_to_bf16(kreg[n], &a, &b);
-        *reinterpret_cast<u32x4_t*>(kl + row * kKRowB + ((c16 ^ (row & 15)) << 4)) = a;
-        *reinterpret_cast<u32x4_t*>(kl + row * kKRowB + (((c16 + 1) ^ (row & 15)) << 4)) = b;
-        fp8x16_to_bf16(vreg[n], &a, &b);
-        *reinterpret_cast<u32x4_t*>(vl + row * kVRowB + (c16 << 4)) = a;
-        *reinterpret_cast<u32x4_t*>(vl + row * kVRowB + ((c16 + 1) << 4)) = b;
+        fp8x16_to_bf16(reg[n], &a, &b);
+        *reinterpret_cast<u32x4_t*>(dst + row * rowb + ((c16 ^ sw) << 4)) = a;
+        *reinterpret_cast<u32x4_t*>(dst + row * rowb + (((c16 + 1) ^ sw) << 4)) = b;
       }
     } else {
 #pragma unroll
       for (int n = 0; n < kCh; ++n) {
         const int chunk = tid + n * NT;
         const int row = chunk >> 4, c16 = chunk & 15;
-        *reinterpret_cast<u32x4_t*>(kl + row * kKRowB + ((c16 ^ (row & 15)) << 4)) = kreg[n];
-        *reinterpret_cast<u32x4_t*>(vl + row * kVRowB + (c16 << 4)) = vreg[n];
+        const int sw = IS_K ? (row & 15) : 0;
+        *reinterpret_cast<u32x4_t*>(dst + row * rowb + ((c16 ^ sw) << 4)) = reg[n];
       }
     }
+  };
+  auto stage_write = [&](int buf) {     // registers -> LDS tile buffer `buf`
+    write_rows(std::true_type{}, buf);
+    write_rows(std::false_type{}, buf);
   };
   // keys this WAVE's 32 rows can see: tiles starting above wave_kmax carry no work for it
   // (a wave whose 32 rows all lie past the end of the sequence — the tail of the last q-block — has no work at all:
@@ -326,17 +339,52 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   // kv_end >= 1 always (lq >= 1, off >= 0): unconditional, with an explicit vmcnt(0) — hipcc's waitcnt pass then KNOWS
   // the Q fragment loads have landed before the loop (with a conditional prologue it assumes they may be pending at the
   // loop head and puts vmcnt waits on their first uses inside QK^T, which drain whatever tile loads are in flight).
-  stage_load(0);
+  // PP: the staged unit is the PAIR p = {K rows of tile p + 1, V rows of tile p} (K runs one tile ahead in LDS)
+  const int nt = (kv_end + kKBlk - 1) / kKBlk;       // key tiles of the workgroup's item (>= 1)
+  auto load_pair = [&](int p) {
+    if (p + 1 < nt) load_rows(std::true_type{}, seq, kvh, k0, lk, (p + 1) * kKBlk);
+    if (p < nt) load_rows(std::false_type{}, seq, kvh, k0, lk, p * kKBlk);
+  };
+  auto write_pair = [&](int p) {
+    if (p + 1 < nt) write_rows(std::true_type{}, (p + 1) & 1);
+    if (p < nt) write_rows(std::false_type{}, p & 1);
+  };
+  if constexpr (PP) load_rows(std::true_type{}, seq, kvh, k0, lk, 0);
+  else stage_load(0);
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
   // a (no-op) use of the Q fragments HERE: without it LLVM sinks their loads into the loop preheader, behind this wait
 #pragma unroll
   for (int ds = 0; ds < 8; ++ds) asm volatile("" : "+v"(qf[ds]));
-  stage_write(0);
+  if constexpr (PP) {
+    write_rows(std::true_type{}, 0);
+    load_pair(0);
+  } else {
+    stage_write(0);
+  }
   __syncthreads();
 
 
   // ---- S^T tile: 2 key blocks x 32 keys; lane = query column ---------------------------------
-  auto qk = [&](f32x16_t (&sacc)[2], const unsigned char* k_lds) {
+  auto qk = [&](f32x16_t (&sacc)[2], const unsigned char* k_lds) __attribute__((always_inline)) {
+    if constexpr (PP) {
+      // the two key blocks' accumulation chains alternate (no MFMA waits for its predecessor's result)
+#pragma unroll
+      for (int ds = 0; ds < 8; ++ds)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+        {
+          bf16x8_t a;
+          if constexpr (VAR & 2) a = qf[(ds + kb) & 7];
+          else a = as_bf16x8(*reinterpret_cast<const u32x4_t*>(k_lds + kb * 32 * kKRowB + kslot[ds]));
+          if constexpr (VAR & 8) {
+            if (ds == 0) sacc[kb] = kZero16;
+            sacc[kb][ds] += (float)a[0];
+          } else {
+            sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ds], ds == 0 ? kZero16 : sacc[kb], 0, 0, 0);
+          }
+        }
+      return;
+    }
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
       // A operand: lane (key row kb*32 + qcol, hi) holds d = ds*16 + 8*hi .. +8 (swizzled 16-byte slot)
@@ -348,7 +396,9 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
         sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
             as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[ds])), qf[ds], sacc[kb], 0, 0, 0);
     }
-    // K fragment reads pinned three ahead of their MFMA (16 ds_read_b128, 16 MFMAs)
+  };
+  // K fragment reads pinned three ahead of their MFMA (16 ds_read_b128, 16 MFMAs)
+  auto pin_qk = [&]() {
     __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
     for (int i = 0; i < 13; ++i) {
@@ -357,7 +407,17 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     }
     __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
   };
-  auto softmax_pv = [&](f32x16_t (&sacc)[2], int kmin_w, const int kt, const unsigned char* v_lds) {
+  // P^T fragments of a tile (B operand of the P.V product): [kb][r0], k-slot (hi, e) <-> acc reg r0*8 + e
+  auto softmax = [&](f32x16_t (&sacc)[2], int kmin_w, const int kt, bf16x8_t (&pf)[2][2]) __attribute__((always_inline)) {
+    if constexpr (VAR & 1) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r0 = 0; r0 < 2; ++r0)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf[kb][r0][e] = (bf16_t)sacc[kb][r0 * 8 + e];
+      return;
+    }
     // ---- online softmax (base 2; the softmax scale is folded into the exponent's FMA) --------------
     // Only tiles that straddle this wave's causal frontier need the per-element mask.
     if (kt + kKBlk - 1 > kmin_w) {
@@ -383,7 +443,12 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
       mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     }
     const float m_new = fmaxf(m_run, mx * scale_log2e);
-    if (__any(m_new > m_run)) {          // some row's running max moved: rescale (exact no-op otherwise)
+    // Deferred rescale (cdna_hip_programming.md T13): O and l are brought to the new maximum only when some row's maximum
+    // grew by more than rescale_thr (log2 units); until then the tile's P are taken against the STALE maximum (P <= 2^thr
+    // instead of <= 1: the same relative rounding, no overflow at thr = 8) and nothing else changes — O / l and LSE = m +
+    // log2 l are the same quantities. The order is the safe one: the previous tile's P.V is complete, the tile's P are
+    // exponentiated after the decision, l and O take the same factor. (rescale_thr = 0: rescale whenever a maximum moves.)
+    if (__any(m_new > m_run + rescale_thr)) {
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       l_run *= alpha;
 #pragma unroll
@@ -393,7 +458,6 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
       m_run = m_new;
     }
     float psum[2] = {0.f, 0.f};
-    bf16x8_t pf[2][2];  // [kb][r0]: P^T fragment (B operand), k-slot (hi, e) <-> acc reg r0*8 + e
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -405,9 +469,10 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
           pf[kb][r0][e] = (bf16_t)p;
         }
     l_run += psum[0] + psum[1];
-
-    // ---- O^T += V^T . P^T : A operand lane (d = lane&31, hi) needs V[key(hi, e)][d] ----------
-    // key(hi, e) = kb*32 + 16*r0 + 4*hi + (e & 3) + 8*(e >> 2): two transpose reads of 4 keys.
+  };
+  // ---- O^T += V^T . P^T : A operand lane (d = lane&31, hi) needs V[key(hi, e)][d] ----------
+  // key(hi, e) = kb*32 + 16*r0 + 4*hi + (e & 3) + 8*(e >> 2): two transpose reads of 4 keys.
+  auto pv = [&](const bf16x8_t (&pf)[2][2], const unsigned char* v_lds) __attribute__((always_inline)) {
     const unsigned char* vb = v_lds + vlane;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -420,7 +485,10 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
               (__attribute__((address_space(3))) s16x4_t*)(p0));
           const s16x4_t a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
               (__attribute__((address_space(3))) s16x4_t*)(p0 + 8 * kVRowB));
-          const s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          if constexpr (VAR & 2) a = __builtin_bit_cast(s16x8_t, qf[(kb * 2 + r0 + db) & 7]);
+          if constexpr (VAR & 8) oacc[db][kb * 2 + r0] += (float)a[0] * (float)pf[kb][r0][0];
+          else
           oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), pf[kb][r0],
                                                              oacc[db], 0, 0, 0);
         }
@@ -440,11 +508,15 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
     // after QK^T: issued at the top of the iteration (a full tile of latency cover) they measured 1-2 % slower.
     f32x16_t sacc[2];
     const bool active = kt <= wave_kmax_s;
-    if (active) qk(sacc, k_lds);
+    if (active) { qk(sacc, k_lds); pin_qk(); }
     __builtin_amdgcn_sched_barrier(0);
     if (more) stage_load(kt + kKBlk);
     __builtin_amdgcn_sched_barrier(0);
-    if (active) softmax_pv(sacc, wave_kmin_s, kt, v_lds);
+    if (active) {
+      bf16x8_t pf[2][2];
+      softmax(sacc, wave_kmin_s, kt, pf);
+      pv(pf, v_lds);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (more) stage_write(buf ^ 1);     // the other buffer was last read one barrier ago
     __syncthreads();
@@ -452,10 +524,132 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   // (Tried on top of this and dropped: a two-score-tile pipeline — QK^T of tile t+1 beside the softmax of tile t,
   // cdna_hip_programming.md T15 — with the interleave pinned block by block: 253-255 registers, 4-5 % SLOWER at
   // 1 x 16,384 than this loop; the rolled loop, 1-3 % slower. profiles/r03_prefill_ab_var{0,1,2}.json.)
-  for (int kt = 0; kt < kv_end; kt += 2 * kKBlk) {
-    tile_step(std::integral_constant<int, 0>{}, kt);
-    if (kt + kKBlk >= kv_end) break;
-    tile_step(std::integral_constant<int, 1>{}, kt + kKBlk);
+  if constexpr (!PP) {
+    for (int kt = 0; kt < kv_end; kt += 2 * kKBlk) {
+      tile_step(std::integral_constant<int, 0>{}, kt);
+      if (kt + kKBlk >= kv_end) break;
+      tile_step(std::integral_constant<int, 1>{}, kt + kKBlk);
+    }
+  } else {
+    static_assert(!PP || NW == 8, "the ping-pong form is an 8-wave shape");
+    // Interval numbering (one interval = the code between two workgroup barriers), half g = hsub (0: waves 0-3, 1: 4-7):
+    //   half 0:  I0 M(0) | I1 SM(0) | I2 M(1) | I3 SM(1) | ...        M(t)  = P.V(t-1) + QK^T(t)      (matrix pipe, LDS reads)
+    //   half 1:  I0 stage| I1 M(0)  | I2 SM(0)| I3 M(1)  | ...        SM(t) = softmax(t) + LDS write of pair t + g
+    //                                                                          + loads of pair t + g + 1 (VALU, LDS writes)
+    // Pair p = {K(p+1), V(p)} may be written during I(2p), I(2p+1) only (its buffers' last readers ran in I(2p-1), its
+    // first reader runs in I(2p+2)): half 0 writes its share in SM(p) = I(2p+1), half 1 in SM(p-1) = I(2p). Every wave
+    // executes the same number of barriers: half 1 has one more in front, half 0 one more at the end.
+    const int g = __builtin_amdgcn_readfirstlane(hsub);
+    // the workgroup barrier as a SCHEDULING fence too: hipcc otherwise sinks the tail of the softmax (exp, cvt) below
+    // the barrier into the matrix interval, and MFMAs of the matrix interval below the next barrier
+    auto pp_barrier = [&]() __attribute__((always_inline)) {
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    if (g) {
+      if constexpr (!(VAR & 64)) {
+        write_pair(0);
+        load_pair(1);
+      }
+      pp_barrier();
+    }
+    // VAR & 64: the pair is staged by the wave in its MATRIX interval instead (pair t in M(t), both halves: M(t) lies
+    // in the pair's window I(2t), I(2t+1) for either half)
+    auto stage = [&](int t) {
+      if constexpr (VAR & 4) return;
+      if constexpr (VAR & 64) return;
+      write_pair(t + g);
+      load_pair(t + g + 1);
+    };
+    auto stage_m = [&](int t) {
+      if constexpr (VAR & 4) return;
+      if constexpr (!(VAR & 64)) return;
+      write_pair(t);
+      load_pair(t + 1);
+    };
+    auto m_begin = [&]() { if constexpr (VAR & 32) __builtin_amdgcn_s_setprio(1); };
+    auto m_end = [&]() { if constexpr (VAR & 32) __builtin_amdgcn_s_setprio(0); };
+    // tiles this wave has work in (its rows' causal frontier); past them it only helps staging
+    const int ntw = wave_kmax_s >= 0 ? min(nt, wave_kmax_s / kKBlk + 1) : 0;
+    f32x16_t sacc[2];
+    bf16x8_t pf[2][2];
+    if (ntw > 0) { qk(sacc, smem); pin_qk(); }
+    __builtin_amdgcn_sched_barrier(0);
+    stage_m(0);
+    pp_barrier();
+    // the M interval's fragment reads stay three MFMAs ahead of their consumer: 32 tr reads (P.V) then 16 b128 reads (QK^T)
+    auto pin_m = [&]() {
+      __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+      for (int i = 0; i < 13; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+    };
+    int t = 0;
+    // (VAR & 16, probe builds: cycle stamps of the two intervals and of the two barrier waits, summed per wave into `lse`)
+    long long ts_sm = 0, ts_w1 = 0, ts_m = 0, ts_w2 = 0;
+    auto stamp = [&]() __attribute__((always_inline)) -> long long {
+      if constexpr (VAR & 16) {
+        __builtin_amdgcn_sched_barrier(0);
+        const long long c = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+        return c;
+      }
+      return 0;
+    };
+    for (; t + 1 < ntw; ++t) {                    // SM(t) | barrier | M(t + 1) = P.V(t) + QK^T(t + 1) | barrier
+      const int par = t & 1;
+      const long long c0 = stamp();
+      softmax(sacc, wave_kmin_s, t * kKBlk, pf);
+      __builtin_amdgcn_sched_barrier(0);
+      stage(t);
+      const long long c1 = stamp();
+      pp_barrier();
+      const long long c2 = stamp();
+      m_begin();
+      pv(pf, smem + par * kBufStride + kKBlk * kKRowB);
+      qk(sacc, smem + (par ^ 1) * kBufStride);
+      pin_m();
+      __builtin_amdgcn_sched_barrier(0);
+      m_end();
+      stage_m(t + 1);
+      const long long c3 = stamp();
+      pp_barrier();
+      const long long c4 = stamp();
+      ts_sm += c1 - c0; ts_w1 += c2 - c1; ts_m += c3 - c2; ts_w2 += c4 - c3;
+    }
+    if constexpr (VAR & 16) {
+      if (lse != nullptr && lane == 0) {
+        float* d = lse + ((size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + wave_all) * 8;
+        d[0] = (float)ts_sm; d[1] = (float)ts_w1; d[2] = (float)ts_m; d[3] = (float)ts_w2; d[4] = (float)t; d[5] = (float)nt;
+      }
+    }
+    if (ntw > 0) {                                // the wave's last tile: SM(t) | barrier | P.V(t) | barrier
+      softmax(sacc, wave_kmin_s, t * kKBlk, pf);
+      __builtin_amdgcn_sched_barrier(0);
+      stage(t);
+      pp_barrier();
+      pv(pf, smem + (t & 1) * kBufStride + kKBlk * kKRowB);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_m(t + 1);
+      pp_barrier();
+      ++t;
+    }
+    for (; t < nt; ++t) {                         // tiles above this wave's rows: staging only
+      stage(t);
+      pp_barrier();
+      stage_m(t + 1);
+      pp_barrier();
+    }
+    if (!g) __syncthreads();
   }
 
   // ---- epilogue: normalise and store O[query][d] ------------------------------------------------
@@ -467,7 +661,7 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
   const float inv = 1.f / l_tot;
   // optional log-sum-exp of the scaled scores per (query, head), natural log (flash-attn's softmax_lse): the running
   // max / sum live in the log2 domain here
-  if (lse != nullptr && q_valid && hi == 0) lse[(int64_t)(q0 + qi) * hq + head] = 0.6931471805599453f * (m_run + log2f(l_tot));
+  if (!(VAR & 16) && lse != nullptr && q_valid && hi == 0) lse[(int64_t)(q0 + qi) * hq + head] = 0.6931471805599453f * (m_run + log2f(l_tot));
   // A lane holds d = db*32 + 8*rg + 4*hi + (0..3) of its query row: 8 bytes per (db, rg), the other half-wave the 8
   // bytes next to them. One v_permlane32_swap per dword trades halves between two neighbouring groups, after which
   // every lane owns 16 contiguous bytes: 8 dwordx4 stores per lane instead of 16 dwordx2 (cdna_hip_programming.md T21;
@@ -517,7 +711,7 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   if (total_q == 0 || num_seqs == 0) return NVL_OK;
   const int64_t tiles = (total_q + kQBlk - 1) / kQBlk + num_seqs;  // upper bound on sum ceil(Lq/128)
   NVL_REQUIRE(tiles < (1ll << 31), "nvl_attn_prefill_varlen: too many query tiles");
-  const size_t lds = (size_t)2 * kTileBytes + 8 * sizeof(int) + (size_t)(num_seqs + 1) * sizeof(int);
+  size_t lds = (size_t)2 * kTileBytes + 8 * sizeof(int) + (size_t)(num_seqs + 1) * sizeof(int);
   const float sl2 = softmax_scale * 1.4426950408889634f;
   hipStream_t s = (hipStream_t)stream;
   // XCD-aware workgroup numbering (see the kernel). Round 2's kernel, measured A/B on MI355X
@@ -533,8 +727,13 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // numbering is +3...11 % on bench-like / ragged batches of 100-1024-token prompts, +-1 % on the long shapes, -2...4 %
   // on launches of > 64 very short sequences => ON by default for 4-wave launches of <= 64 sequences; NVL_PREFILL_XCD=0|1
   // forces it off / on for every launch.
-  static int xcd_env = -2, waves = -1;
+  static int xcd_env = -2, waves = -1, pp = 0;
+  static float thr = 8.f;
   if (xcd_env == -2) {
+    const char* pe = getenv("NVL_PREFILL_PP");      // 1: the ping-pong form of the 8-wave loop (measured slower: off)
+    pp = pe && pe[0] == '1';
+    const char* te = getenv("NVL_PREFILL_RESCALE_THR");   // log2 units; 0 = rescale whenever a row's maximum moves
+    if (te) thr = (float)atof(te);
     const char* e = getenv("NVL_PREFILL_XCD");
     xcd_env = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : -1;
     const char* w = getenv("NVL_PREFILL_WAVES");
@@ -544,6 +743,7 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   const bool eight_ok = (num_q_heads / num_kv_heads) % 2 == 0;
   const int xcd_map = xcd_env >= 0 ? xcd_env : ((want == 4 || !eight_ok) && num_seqs <= 64 ? 1 : 0);
   const bool eight = want == 8 && !xcd_map && eight_ok;
+  if (eight && pp) lds += 65536 - kTileBytes;      // the ping-pong form's second tile buffer starts at 64 KiB
   dim3 grid((unsigned)(eight ? num_q_heads / 2 : num_q_heads), (unsigned)tiles);
   if (xcd_map) {
     const int64_t groups = tiles * num_kv_heads;
@@ -559,21 +759,50 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
     const size_t want = lds < 160 * 1024 ? lds + 16 * 1024 : lds;   // headroom: num_seqs moves it by a few KiB
     const size_t cap = want > 160 * 1024 ? 160 * 1024 : want;
     NVL_REQUIRE(lds <= 160 * 1024, "nvl_attn_prefill_varlen: %d sequences need %zu B of LDS (> 160 KiB)", num_seqs, lds);
-#define NVL_PF_ATTR(P, K8, NWV)                                                                            \
-    (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<P, K8, NWV>),                  \
+#define NVL_PF_ATTR(P, K8, NWV, PPV)                                                                       \
+    (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<P, K8, NWV, PPV>),             \
                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)cap) != hipSuccess)
-    if (NVL_PF_ATTR(true, false, 4) || NVL_PF_ATTR(true, true, 4) || NVL_PF_ATTR(false, false, 4) ||
-        NVL_PF_ATTR(true, false, 8) || NVL_PF_ATTR(true, true, 8) || NVL_PF_ATTR(false, false, 8)) {
+    if (NVL_PF_ATTR(true, false, 4, false) || NVL_PF_ATTR(true, true, 4, false) || NVL_PF_ATTR(false, false, 4, false) ||
+        NVL_PF_ATTR(true, false, 8, false) || NVL_PF_ATTR(true, true, 8, false) || NVL_PF_ATTR(false, false, 8, false) ||
+        NVL_PF_ATTR(true, false, 8, true) || NVL_PF_ATTR(true, true, 8, true) || NVL_PF_ATTR(false, false, 8, true)) {
       nvl_set_error("nvl_attn_prefill_varlen: cannot reserve %zu B of LDS", cap);
       return NVL_ELAUNCH;
     }
 #undef NVL_PF_ATTR
     lds_cap = cap;
   }
-#define NVL_PF_LAUNCH(P, K8, NWV)                                                                                      \
-  hipLaunchKernelGGL((prefill_attn_kernel<P, K8, NWV>), grid, dim3(NWV * 64), lds, s, (const bf16_t*)q,                 \
+#define NVL_PF_LAUNCH3(P, K8, NWV, PPV)                                                                                \
+  hipLaunchKernelGGL((prefill_attn_kernel<P, K8, NWV, PPV>), grid, dim3(NWV * 64), lds, s, (const bf16_t*)q,            \
                      (const bf16_t*)k, (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k,        \
-                     block_tables, bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map, lse)
+                     block_tables, bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map, lse, thr)
+#ifdef NVL_PROBES
+  {   // deletion probes of the packed ping-pong kernel (wrong results by construction): NVL_PREFILL_VAR bits
+      // 1 no softmax, 2 no LDS fragment reads, 4 no staging, 8 no MFMAs
+    static int var = -1;
+    if (var < 0) { const char* ve = getenv("NVL_PREFILL_VAR"); var = ve ? atoi(ve) : 0; }
+    if (var && eight && pp && !paged) {
+#define NVL_PF_VAR(V)                                                                                                   \
+      case V:                                                                                                          \
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_attn_kernel<false, false, 8, true, V>),             \
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                                   \
+        hipLaunchKernelGGL((prefill_attn_kernel<false, false, 8, true, V>), grid, dim3(512), lds, s, (const bf16_t*)q, \
+                           (const bf16_t*)k, (const bf16_t*)v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, \
+                           block_tables, bt_stride, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads, block_size, sl2, xcd_map, lse, thr); \
+        return nvl_check_launch("nvl_attn_prefill_varlen");
+      switch (var) {
+        NVL_PF_VAR(1) NVL_PF_VAR(2) NVL_PF_VAR(3) NVL_PF_VAR(4) NVL_PF_VAR(5) NVL_PF_VAR(6) NVL_PF_VAR(7) NVL_PF_VAR(8)
+        NVL_PF_VAR(9) NVL_PF_VAR(12) NVL_PF_VAR(13) NVL_PF_VAR(14) NVL_PF_VAR(15) NVL_PF_VAR(16) NVL_PF_VAR(17) NVL_PF_VAR(18) NVL_PF_VAR(20) NVL_PF_VAR(23) NVL_PF_VAR(32) NVL_PF_VAR(64) NVL_PF_VAR(96) NVL_PF_VAR(48) NVL_PF_VAR(80) NVL_PF_VAR(112)
+        default: break;
+      }
+#undef NVL_PF_VAR
+    }
+  }
+#endif
+#define NVL_PF_LAUNCH(P, K8, NWV)                                              \
+  do {                                                                         \
+    if (NWV == 8 && pp) NVL_PF_LAUNCH3(P, K8, 8, true);                        \
+    else NVL_PF_LAUNCH3(P, K8, NWV, false);                                    \
+  } while (0)
   if (paged && kv_dtype == NVL_KV_FP8) {
     if (eight) NVL_PF_LAUNCH(true, true, 8); else NVL_PF_LAUNCH(true, true, 4);
   } else if (paged) {
@@ -582,5 +811,6 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
     if (eight) NVL_PF_LAUNCH(false, false, 8); else NVL_PF_LAUNCH(false, false, 4);
   }
 #undef NVL_PF_LAUNCH
+#undef NVL_PF_LAUNCH3
   return nvl_check_launch("nvl_attn_prefill_varlen");
 }
