@@ -753,6 +753,71 @@ def test_prefill_softmax_rescale_branch(ops):
 
 
 
+_RESCALE_CHILD = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+from nano_vllm_amd import ops
+ops.load_library()
+d = torch.load(sys.argv[2])
+out = {}
+for name, (q, k, v, n) in d.items():
+    cu = torch.tensor([0, n], dtype=torch.int32, device="cuda")
+    lse = torch.zeros(n, q.shape[1], dtype=torch.float32, device="cuda")
+    o = ops.attn_prefill_varlen(q.cuda(), k.cuda(), v.cuda(), cu, cu, n, 128 ** -0.5, lse=lse)
+    out[name] = (o.cpu(), lse.cpu())
+torch.save(out, sys.argv[3])
+"""
+
+
+def test_prefill_deferred_rescale_equals_immediate_rescale(ops, tmp_path):
+    """The prefill kernel brings O / l to a new row maximum only when it grew by more than 8 (log2 units) since the last
+    rescale (cdna_hip_programming.md T13; flash-attn rescales whenever it moves). Guide rule 26: a passing comparison on
+    bounded random data says nothing about the branch — so three inputs, each run in a child process per threshold
+    (NVL_PREFILL_RESCALE_THR is read once): plain random data (maxima creep: deferred path only), one key that lifts a
+    query's maximum by ~5 (still deferred: P up to 2^5 against the stale maximum) and one that lifts it by far more than
+    the threshold at a late tile (the branch). THR = 0 == THR = 8 to rounding, and both == the oracle."""
+    import subprocess
+    import sys
+    hq, hkv, n = 8, 4, 2304          # 8-wave shape (>= 2048 rows), several 64-key tiles after the spikes
+    gen = g(61)
+    cases = {}
+    for name, gain in (("random", 0.0), ("small_jump", 0.62), ("big_jump", 4.0)):
+        q = torch.randn(n, hq, 128, generator=gen).to(BF16)
+        k = torch.randn(n, hkv, 128, generator=gen).to(BF16)
+        v = torch.randn(n, hkv, 128, generator=gen).to(BF16)
+        if gain:                     # key 1500 aligned with query 2000 of head 2 (kv head 1): raw score ~ gain * |q|^2
+            k[1500, 1] = (q[2000, 2].float() * gain).to(BF16)
+        cases[name] = (q, k, v, n)
+    inp = tmp_path / "in.pt"
+    torch.save(cases, inp)
+    res = {}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for thr in ("0", "8"):
+        outp = tmp_path / f"out{thr}.pt"
+        r = subprocess.run([sys.executable, "-c", _RESCALE_CHILD, root, str(inp), str(outp)],
+                           env=dict(os.environ, NVL_PREFILL_RESCALE_THR=thr), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[thr] = torch.load(outp)
+    scale = 128 ** -0.5
+    for name, (q, k, v, _) in cases.items():
+        cu = _cu([n])
+        o_ref, lse_ref = ref.flash_attn_varlen_func(q, k, v, n, cu, n, cu, scale, True, None, return_softmax_lse=True)
+        amax = o_ref.float().abs().max().item()
+        (o0, l0), (o8, l8) = res["0"][name], res["8"][name]
+        for o, lse in ((o0, l0), (o8, l8)):
+            assert (o.float() - o_ref.float()).abs().max().item() <= 2e-2 * amax + 1e-3, name
+            assert float((lse - lse_ref).abs().max()) <= 1e-2, name
+        assert (o0.float() - o8.float()).abs().max().item() <= 1e-2 * amax + 1e-3, name     # both are roundings of one value
+        assert float((l0 - l8).abs().max()) <= 1e-3, name
+    # the jumps really are what the docstring says (log2 units, query 2000 of head 2 against the rest of its row)
+    q, k, _, _ = cases["small_jump"]
+    s = (q[2000, 2].float() @ k[:2001, 1].float().T) * scale * 1.4426950408889634
+    assert 2.0 < (s[1500] - torch.cat([s[:1500], s[1501:]]).max()).item() < 8.0
+    q, k, _, _ = cases["big_jump"]
+    s = (q[2000, 2].float() @ k[:2001, 1].float().T) * scale * 1.4426950408889634
+    assert (s[1500] - torch.cat([s[:1500], s[1501:]]).max()).item() > 16.0
+
+
 def _oracle_attend_chunked(q, k, v, scale, off, chunk=1024):
     """oracle/ops.py::_attend over query blocks (its [Hq, Lq, Lk] fp32 score tensor would not fit at 16 k): rows
     [i0, i1) of a bottom-right aligned causal problem see keys j <= i + off."""
