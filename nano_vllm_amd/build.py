@@ -22,6 +22,7 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-fno-gpu-rdc"]
 if os.environ.get("NVL_PROBES") == "1":       # probe build: the kernels' measurement switches (NVL_WIDE_DBG / _DEBUG) exist
     FLAGS.append("-DNVL_PROBES")
+    FLAGS += os.environ.get("NVL_PROBE_FLAGS", "").split()      # e.g. -DNVL_PF_PACKED: a compile-time variant under A/B
     subprocess.run([sys.executable, os.path.join(HERE, "..", "tools", "gen_wide_asm.py"), "--probes"], check=True)
 
 
