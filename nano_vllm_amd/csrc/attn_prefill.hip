@@ -356,16 +356,14 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
             as_bf16x8(*reinterpret_cast<const u32x4_t*>(kr + kslot[ds])), qf[ds], sacc[kb], 0, 0, 0);
     }
     // K fragment reads pinned three ahead of their MFMA (16 ds_read_b128, 16 MFMAs)
-#ifndef NVL_PF_KAHEAD
-#define NVL_PF_KAHEAD 3
-#endif
-    __builtin_amdgcn_sched_group_barrier(0x100, NVL_PF_KAHEAD, 0);
+    // (five ahead, and the exp / sum pairs as v_pk_fma_f32 / v_pk_add_f32: both within noise, profiles/README.md round 6)
+    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
 #pragma unroll
-    for (int i = 0; i < 16 - NVL_PF_KAHEAD; ++i) {
+    for (int i = 0; i < 13; ++i) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
-    __builtin_amdgcn_sched_group_barrier(0x008, NVL_PF_KAHEAD, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
   };
   auto softmax_pv = [&](f32x16_t (&sacc)[2], int kmin_w, const int kt, const unsigned char* v_lds) {
     // ---- online softmax (base 2; the softmax scale is folded into the exponent's FMA) --------------
@@ -411,33 +409,17 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
       m_run = m_new;
     }
     float psum[2] = {0.f, 0.f};
-#ifdef NVL_PF_PACKED
-    __attribute__((ext_vector_type(2))) float ps2 = {0.f, 0.f};
-#endif
     bf16x8_t pf[2][2];  // [kb][r0]: P^T fragment (B operand), k-slot (hi, e) <-> acc reg r0*8 + e
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int r0 = 0; r0 < 2; ++r0)
 #pragma unroll
-#ifdef NVL_PF_PACKED
-        for (int e = 0; e < 8; e += 2) {      // two scores per VALU instruction: v_pk_fma_f32, v_pk_add_f32 (probe builds)
-          typedef __attribute__((ext_vector_type(2))) float f32x2_t_;
-          const f32x2_t_ x = f32x2_t_{sacc[kb][r0 * 8 + e], sacc[kb][r0 * 8 + e + 1]} * f32x2_t_{scale_log2e, scale_log2e} -
-                             f32x2_t_{m_run, m_run};
-          const f32x2_t_ p = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
-          ps2 += p;
-          pf[kb][r0][e] = (bf16_t)p[0];
-          pf[kb][r0][e + 1] = (bf16_t)p[1];
-        }
-    psum[0] = ps2[0]; psum[1] = ps2[1];
-#else
         for (int e = 0; e < 8; ++e) {
           const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][r0 * 8 + e], scale_log2e, -m_run));
           psum[0] += p;
           pf[kb][r0][e] = (bf16_t)p;
         }
-#endif
     l_run += psum[0] + psum[1];
 
     // ---- O^T += V^T . P^T : A operand lane (d = lane&31, hi) needs V[key(hi, e)][d] ----------
