@@ -507,6 +507,11 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
 
 }  // namespace
 
+// attn_prefill64.hip: the 64-rows-per-wave shape (one wave per SIMD, generated asm main loop) for packed long prompts
+int nvl_prefill_w64_launch(const void* q, const void* k, const void* v, int64_t k_tok_stride, int64_t v_tok_stride,
+                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, void* out, int64_t total_q, int num_seqs,
+                           int num_q_heads, int num_kv_heads, float scale_log2e, float* lse, float rescale_thr, hipStream_t s);
+
 extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void* v, int64_t k_tok_stride,
                                        int64_t v_tok_stride, const int32_t* cu_seqlens_q,
                                        const int32_t* cu_seqlens_k, const int32_t* block_tables, int64_t bt_stride,
@@ -549,9 +554,11 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // numbering is +3...11 % on bench-like / ragged batches of 100-1024-token prompts, +-1 % on the long shapes, -2...4 %
   // on launches of > 64 very short sequences => ON by default for 4-wave launches of <= 64 sequences; NVL_PREFILL_XCD=0|1
   // forces it off / on for every launch.
-  static int xcd_env = -2, waves = -1;
+  static int xcd_env = -2, waves = -1, w64 = 0;
   static float thr = 8.f;
   if (xcd_env == -2) {
+    const char* we = getenv("NVL_PREFILL_W64");     // the 64-rows-per-wave shape: 0 never, 1 long packed prompts, 2 every packed launch
+    if (we) w64 = we[0] - '0';
     const char* te = getenv("NVL_PREFILL_RESCALE_THR");   // log2 units; 0 = rescale whenever a row's maximum moves
     if (te) thr = (float)atof(te);
     const char* e = getenv("NVL_PREFILL_XCD");
@@ -559,6 +566,9 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
     const char* w = getenv("NVL_PREFILL_WAVES");
     waves = (w && w[0] == '8') ? 8 : ((w && w[0] == '4') ? 4 : 0);
   }
+  if (w64 && (max_seqlen_q >= 2048 || w64 == 2) && num_seqs <= 64 && !paged && !waves)
+    return nvl_prefill_w64_launch(q, k, v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, out, total_q, num_seqs,
+                                  num_q_heads, num_kv_heads, sl2, lse, thr, s);
   const int want = waves ? waves : (max_seqlen_q >= 2048 ? 8 : 4);
   const bool eight_ok = (num_q_heads / num_kv_heads) % 2 == 0;
   const int xcd_map = xcd_env >= 0 ? xcd_env : ((want == 4 || !eight_ok) && num_seqs <= 64 ? 1 : 0);
