@@ -554,10 +554,10 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // numbering is +3...11 % on bench-like / ragged batches of 100-1024-token prompts, +-1 % on the long shapes, -2...4 %
   // on launches of > 64 very short sequences => ON by default for 4-wave launches of <= 64 sequences; NVL_PREFILL_XCD=0|1
   // forces it off / on for every launch.
-  static int xcd_env = -2, waves = -1, w64 = 0;
+  static int xcd_env = -2, waves = -1, w64 = 1;
   static float thr = 8.f;
   if (xcd_env == -2) {
-    const char* we = getenv("NVL_PREFILL_W64");     // the 64-rows-per-wave shape: 0 never, 1 long packed prompts, 2 every packed launch
+    const char* we = getenv("NVL_PREFILL_W64");     // the 64-rows-per-wave shape: 0 never, 1 long packed prompts (default), 2 every packed launch
     if (we) w64 = we[0] - '0';
     const char* te = getenv("NVL_PREFILL_RESCALE_THR");   // log2 units; 0 = rescale whenever a row's maximum moves
     if (te) thr = (float)atof(te);
@@ -566,7 +566,10 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
     const char* w = getenv("NVL_PREFILL_WAVES");
     waves = (w && w[0] == '8') ? 8 : ((w && w[0] == '4') ? 4 : 0);
   }
-  if (w64 && (max_seqlen_q >= 2048 || w64 == 2) && num_seqs <= 64 && !paged && !waves)
+  // the one-wave-per-SIMD shape with the generated asm main loop (attn_prefill64.hip): packed K / V, long prompts (its
+  // 256-row q tiles waste rows on short sequences: mean length >= 1024 as well). Measured +3 % (8 x 2048, G = 8) ... +10 %
+  // (1 x 16,384) over the 8-wave loop, profiles/r06_prefill_w64_asm_*.txt
+  if (w64 && ((max_seqlen_q >= 2048 && total_q >= (int64_t)num_seqs * 1024) || w64 == 2) && num_seqs <= 64 && !paged && !waves)
     return nvl_prefill_w64_launch(q, k, v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, out, total_q, num_seqs,
                                   num_q_heads, num_kv_heads, sl2, lse, thr, s);
   const int want = waves ? waves : (max_seqlen_q >= 2048 ? 8 : 4);

@@ -181,3 +181,7 @@ def test_generated_asm_cores_are_fresh():
     import sys
     rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_wide_asm.py"), "--check"]).returncode
     assert rc == 0, "run `python tools/gen_wide_asm.py` and commit the .inc files"
+    # the prefill attention's main loop (csrc/attn_prefill64_core.inc) likewise
+    env = {k: v for k, v in os.environ.items() if not k.startswith("NVL_PF64_")}
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_prefill_asm.py"), "--core", "--check"], env=env).returncode
+    assert rc == 0, "run `python tools/gen_prefill_asm.py --core` and commit csrc/attn_prefill64_core.inc"

@@ -886,6 +886,19 @@ def test_prefill_other_workgroup_shape_passes_the_same_tests():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+@pytest.mark.slow      # (20 s: the prefill tests once more with the one-wave-per-SIMD shape forced for every packed launch)
+def test_prefill_w64_shape_passes_the_same_tests():
+    """attn_prefill64.hip (generated asm main loop, 64 rows per wave) serves packed launches of long prompts by default — the
+    16 k / 4 k comparisons and the deferred-rescale test of this file run on it; here every packed launch of the file takes it
+    (NVL_PREFILL_W64=2): ragged short sequences, rows past the end of a 256-row tile, masks on every tile, the LSE output."""
+    import subprocess
+    import sys
+    env = dict(os.environ, NVL_PREFILL_W64="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-q", "-x", "-k",
+                        "prefill and not other_workgroup_shape and not w64_shape"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 # ------------------------------------------------------------------------------------------
 # Opt-in fp8 (OCP e4m3) KV cache (SURVEY.md §8f-4). Oracle = the same restatement evaluated on a cache whose values
 # went through torch's own float8_e4m3fn cast: the store must reproduce that cast BIT FOR BIT (round to nearest

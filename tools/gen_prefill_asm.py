@@ -112,8 +112,9 @@ def finish_chunk(st: Stream, cur, X, c, packed=False):
     base = S(cur, X, kb)
     x0, x1 = base + 2 * k, base + 2 * k + 1
     t0, t1 = T[2 * X], T[2 * X + 1]
-    st.emit(f"v_exp_f32 {vr(t0)}, {vr(x0)}")
-    st.emit(f"v_exp_f32 {vr(t1)}, {vr(x1)}")
+    op = "v_mov_b32" if os.environ.get("NVL_PF64_NOEXP") == "1" else "v_exp_f32"     # (probe: what the transcendentals cost)
+    st.emit(f"{op} {vr(t0)}, {vr(x0)}")
+    st.emit(f"{op} {vr(t1)}, {vr(x1)}")
     if c == 0:
         st.emit(f"v_mov_b32 {vr(PS[X][0])}, {vr(t0)}")
         st.emit(f"v_mov_b32 {vr(PS[X][1])}, {vr(t1)}")
@@ -282,21 +283,38 @@ def rescale_block(st: Stream, X):
             st.emit(f"v_accvgpr_write_b32 {ar(r)}, {vr(t[i])}")
 
 
+MNEW = (188, 189)              # per block: the candidate maximum of the tile being started
+DTMP = (190, 191)
+DFLAG = ("s[58:59]", "s[60:61]")   # per block: lanes whose maximum grew by more than the threshold
+
+
+def decide_piece(st: Stream, X, piece):
+    """the decision of block X in four pieces (positions 4 .. 7 of phase 2, after the maxima): cross-half maximum, candidate
+    maximum, lanes beyond the threshold -> DFLAG. Other instructions of the position separate the pieces (the permlane needs two
+    wait states behind the v_mov)."""
+    a, b = MNEW[X], DTMP[X]
+    if DEL & 4:
+        return
+    if piece == 0:
+        st.emit(f"v_max_f32 {vr(a)}, {vr(MX[X][0])}, {vr(MX[X][1])}")
+        st.emit(f"v_mov_b32 {vr(b)}, {vr(a)}")
+    elif piece == 1:
+        st.emit(f"v_permlane32_swap_b32 {vr(a)}, {vr(b)}")
+    elif piece == 2:
+        st.emit(f"v_max_f32 {vr(a)}, {vr(a)}, {vr(b)}")
+        st.emit(f"v_mul_f32 {vr(a)}, s_scale, {vr(a)}")
+        st.emit(f"v_max_f32 {vr(a)}, {vr(a)}, {vr(M_RUN[X])}")          # m_new
+    else:
+        st.emit(f"v_add_f32 {vr(b)}, s_thr, {vr(M_RUN[X])}")
+        st.emit(f"v_cmp_gt_f32_e64 {DFLAG[X]}, {vr(a)}, {vr(b)}")
+
+
 def decide(st: Stream, nxt, X, tag):
-    """the deferred-rescale decision of block X for the tile whose x = S c - m_stale sit in score buffer nxt"""
-    a, b = TMPX[1], TMPX[2]
-    st.emit(f"v_max_f32 {vr(a)}, {vr(MX[X][0])}, {vr(MX[X][1])}")
-    st.emit(f"v_mov_b32 {vr(b)}, {vr(a)}")
-    st.emit("s_nop 1")
-    st.emit(f"v_permlane32_swap_b32 {vr(a)}, {vr(b)}")
-    st.emit("s_nop 0")
-    st.emit(f"v_max_f32 {vr(a)}, {vr(a)}, {vr(b)}")
-    st.emit(f"v_mul_f32 {vr(a)}, s_scale, {vr(a)}")
-    st.emit(f"v_max_f32 {vr(a)}, {vr(a)}, {vr(M_RUN[X])}")          # m_new
-    st.emit(f"v_add_f32 {vr(b)}, s_thr, {vr(M_RUN[X])}")
-    st.emit(f"v_cmp_gt_f32 vcc, {vr(a)}, {vr(b)}")
-    st.emit(f"s_cbranch_vccz SKIP_{tag}_%=")
-    # rare: bring O, l and the tile's x to the new maximum
+    """after the step's last P.V MFMA: if some row's maximum grew beyond the threshold (DFLAG, rare), bring O, l and the next
+    tile's x (taken against the stale maximum) to the new one"""
+    a, b = MNEW[X], DTMP[X]
+    st.emit(f"s_cmp_lg_u64 {DFLAG[X]}, 0")
+    st.emit(f"s_cbranch_scc0 SKIP_{tag}_%=")
     st.emit("s_nop 15")
     st.emit(f"v_sub_f32 {vr(b)}, {vr(M_RUN[X])}, {vr(a)}")            # d = m_old - m_new <= 0
     st.emit(f"v_exp_f32 {vr(TMPX[0])}, {vr(b)}")
@@ -315,20 +333,22 @@ NF1 = 12        # finish chunks per block done in phase 1; the rest ride in the 
 
 
 def phase1_real(st: Stream, cur, nxt, kbuf_next, vbuf_cur, nxt_tile):
+    """A gap: block A's finish chunk (+ a staging request every second position), the wait for fragment h; B gap: the read of
+    fragment h + 3 and block B's chunk — 6-7 fillers either side"""
     for h in range(16):
+        if h < NF1:
+            finish_chunk(st, cur, 0, h)
+        if h % 2 == 0:
+            stage_load(st, h // 2)
+        if nxt_tile:
+            st.wait_for(f"f{h & 3}")
+            mfma_qk(st, nxt, 0, h, h & 3)
         slot = (h + 3) & 3
         if h + 3 < 16:
             if nxt_tile:
                 read_k(st, h + 3, kbuf_next, slot)
         else:
             read_v(st, h + 3 - 16, vbuf_cur, slot)
-        if h % 2 == 0:
-            stage_load(st, h // 2)
-        if h < NF1:
-            finish_chunk(st, cur, 0, h)
-        if nxt_tile:
-            st.wait_for(f"f{h & 3}")
-            mfma_qk(st, nxt, 0, h, h & 3)
         if h < NF1:
             finish_chunk(st, cur, 1, h)
         if nxt_tile:
@@ -351,11 +371,12 @@ def fma1(st: Stream, nxt, X, e):
 
 def phase2_real(st: Stream, cur, nxt, kbuf_w, vbuf_cur, vbuf_w, nxt_tile, masked):
     for j in range(16):
-        if j + 3 < 16:
-            read_v(st, j + 3, vbuf_cur, (j + 3) & 3)
-        if j >= 8:
-            stage_write(st, j - 8, kbuf_w, vbuf_w)
         for X in (0, 1):
+            if X == 1:
+                if j + 3 < 16:
+                    read_v(st, j + 3, vbuf_cur, (j + 3) & 3)
+                if j >= 8:
+                    stage_write(st, j - 8, kbuf_w, vbuf_w)
             if nxt_tile:
                 if masked and j in (0, 2):
                     mask_tuple(st, nxt, X, j >> 1)
@@ -368,6 +389,8 @@ def phase2_real(st: Stream, cur, nxt, kbuf_w, vbuf_cur, vbuf_w, nxt_tile, masked
             if nxt_tile:
                 for e in fma_elems(j):
                     fma1(st, nxt, X, e)
+                if 8 <= j < 12:
+                    decide_piece(st, X, j - 8)
             if X == 0:
                 st.wait_for(f"f{j & 3}")
             mfma_pv(st, cur, X, j, j & 3)
@@ -516,7 +539,7 @@ def core_include():
     for l in st.ins:
         lines.append(pat.sub(lambda m: SREG[m.group(1)], l))
     body = "\n".join(f'    "{l}\\n"' for l in lines)
-    clob = ", ".join([f'"v{i}"' for i in range(0, 192)] + [f'"a{i}"' for i in range(128, 224)] + [f'"s{i}"' for i in range(40, 58)])
+    clob = ", ".join([f'"v{i}"' for i in range(0, 192)] + [f'"a{i}"' for i in range(128, 224)] + [f'"s{i}"' for i in range(40, 62)])
     return f"""// GENERATED by tools/gen_prefill_asm.py — do not edit; the generator's docstring describes the schedule.
 // {len(lines)} instructions (two plain steps, two masked steps, two last steps, prologue).
 #define NVL_PF64_CORE_ASM \\
@@ -645,7 +668,7 @@ if __name__ == "__main__":
         print(out, text.count("\\n"), "instructions")
     if "--probe" in sys.argv:
         src, n = probe_source()
-        out = os.path.join(ROOT, "tools", "probes", "attn_stream_probe.hip")
+        out = os.path.join(ROOT, "tools", "probes", os.environ.get("NVL_PF64_PROBE_NAME", "attn_stream_probe") + ".hip")
         with open(out, "w") as fh:
             fh.write(src)
         print(out, n, "instructions per two steps")
