@@ -12,13 +12,13 @@ kt = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
 dur = {}
 for f in kt:
     for row in csv.DictReader(open(f, newline="")):
-        if "prefill_attn" in row.get("Kernel_Name", ""):
+        if "prefill_" in row.get("Kernel_Name", ""):
             dur[row["Dispatch_Id"]] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"]), row.get("Grid_Size", row.get("Grid_Size_X", "")))
 by = defaultdict(lambda: defaultdict(float))
 grid_of = {}
 for f in cc:
     for row in csv.DictReader(open(f, newline="")):
-        if "prefill_attn" not in row.get("Kernel_Name", ""):
+        if "prefill_" not in row.get("Kernel_Name", ""):
             continue
         key = row.get("Grid_Size", "")
         by[(key, row["Dispatch_Id"])][row["Counter_Name"]] += float(row.get("Counter_Value", 0) or 0)
