@@ -569,7 +569,9 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // the one-wave-per-SIMD shape with the generated asm main loop (attn_prefill64.hip): packed K / V, long prompts (its
   // 256-row q tiles waste rows on short sequences: mean length >= 1024 as well). Measured +3 % (8 x 2048, G = 8) ... +10 %
   // (1 x 16,384) over the 8-wave loop, profiles/r06_prefill_w64_asm_*.txt
-  if (w64 && ((max_seqlen_q >= 2048 && total_q >= (int64_t)num_seqs * 1024) || w64 == 2) && num_seqs <= 64 && !paged && !waves)
+  // (its tile offsets are 32-bit buffer offsets: the packed K / V of the launch must span < 2 GiB)
+  const bool w64_fits = total_q * (k_tok_stride > v_tok_stride ? k_tok_stride : v_tok_stride) * 2 < (1ll << 31);
+  if (w64 && ((max_seqlen_q >= 2048 && total_q >= (int64_t)num_seqs * 1024) || w64 == 2) && num_seqs <= 64 && !paged && !waves && w64_fits)
     return nvl_prefill_w64_launch(q, k, v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, out, total_q, num_seqs,
                                   num_q_heads, num_kv_heads, sl2, lse, thr, s);
   const int want = waves ? waves : (max_seqlen_q >= 2048 ? 8 : 4);
