@@ -105,7 +105,7 @@ def _prompts(n, lo, hi, vocab, seed):
             for _ in range(n)]
 
 
-@pytest.mark.parametrize("eager", [True, False])
+@pytest.mark.parametrize("eager", [pytest.param(True, marks=pytest.mark.slow), False])
 def test_tiny_model_greedy_parity(tiny_ckpt, eager):
     prompts = _prompts(6, 5, 600, 512, seed=3)
     max_tokens = [24, 40, 8, 33, 1, 17]
@@ -154,7 +154,7 @@ def test_tiny_model_chunked_prefill_and_preemption(tiny_ckpt):
 # (`rkey` = ordinal | position << 32 in prefill AND decode images, through the lookahead's pre-staged steps), the
 # graph-captured sampler reading keys/temperatures from the static device block, mid-prefill chunk rows, and mixed
 # greedy / sampled batches.
-@pytest.mark.parametrize("eager", [True, False])
+@pytest.mark.parametrize("eager", [pytest.param(True, marks=pytest.mark.slow), False])   # (eager: --slow; the captured graph takes the same kernels)
 def test_tiny_model_sampled_parity_draws_replayed(tiny_ckpt, eager):
     prompts = _prompts(7, 5, 600, 512, seed=3)
     max_tokens = [24, 40, 8, 33, 1, 17, 29]
@@ -186,6 +186,7 @@ def test_tiny_model_sampled_parity_through_chunked_prefill_and_preemption(tiny_c
                                                 max_num_seqs=8, max_num_batched_tokens=640), sum(max_tokens))
 
 
+@pytest.mark.slow      # (27 s: 320 concurrent sequences in the 512-row bucket; the 256-row bench width stays in the default suite)
 def test_tiny_model_batch_above_256_rows_parity(tiny_ckpt):
     """The reference's DEFAULT `max_num_seqs` is 512 (config.py:11): 320 concurrent sequences put every decode step in the
     512-row hipGraph bucket — staging image, per-step attention plan, the GEMMs' row groups (20 row tiles), the sampler and
@@ -203,7 +204,7 @@ def test_tiny_model_batch_above_256_rows_parity(tiny_ckpt):
     assert v.sampled_rows >= 100 * 6
 
 
-@pytest.mark.parametrize("eager", [True, False])
+@pytest.mark.parametrize("eager", [pytest.param(True, marks=pytest.mark.slow), False])   # (eager: --slow; the captured graph takes the same kernels)
 def test_sequences_that_end_exactly_on_max_model_len_and_on_block_edges(tiny_ckpt, eager):
     """Edges of the paged layout end to end: a sequence whose last token fills `max_model_len` exactly (the widest block
     table the staging image carries: prompt 500 + 12 = 512 = two full blocks), one that ends exactly on a block edge (255 +
@@ -219,8 +220,9 @@ def test_sequences_that_end_exactly_on_max_model_len_and_on_block_edges(tiny_ckp
            sum(max_tokens))
 
 
-@pytest.mark.parametrize("name,eager", [("qwen3-tiny", True), ("qwen3-tiny", False), ("qwen3-tiny-untied", False),
-                                        ("qwen3-tiny-g8", False), ("qwen3-tiny-g5", False)])
+@pytest.mark.parametrize("name,eager", [pytest.param("qwen3-tiny", True, marks=pytest.mark.slow), ("qwen3-tiny", False),
+                                        pytest.param("qwen3-tiny-untied", False, marks=pytest.mark.slow),
+                                        pytest.param("qwen3-tiny-g8", False, marks=pytest.mark.slow), ("qwen3-tiny-g5", False)])
 def test_shared_system_prompt_runs_the_shared_prefix_attention_pass(name, eager, monkeypatch):
     """BASELINE config 3 in small: nine requests start with the same 530 tokens and one has nothing in common with them.
     The token budget lets the first prefill step take three of them — they compute the prefix themselves and keep private
@@ -676,7 +678,7 @@ def test_lookahead_reproduces_the_serial_engine(tiny_ckpt, monkeypatch):
     assert run(0.8) == run(0.8, NVL_LOOKAHEAD="0")
 
 
-@pytest.mark.parametrize("eager", [True, False])
+@pytest.mark.parametrize("eager", [pytest.param(True, marks=pytest.mark.slow), False])   # (eager: --slow; the captured graph takes the same kernels)
 def test_kvcache_block_size_512_with_a_shared_system_prompt(eager, monkeypatch):
     """`kvcache_block_size` may be any multiple of 256 (config.py:22). 512-token blocks end to end: KV store and paged
     prefill across 512-token blocks, prefix-cache hits on two full 512-token blocks (block_manager.py:58-82 hashes whole

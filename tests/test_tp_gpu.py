@@ -189,7 +189,7 @@ def tiny_ckpt():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("mode", ["p2p-graph", "p2p-eager", "group-eager"])
+@pytest.mark.parametrize("mode", ["p2p-graph", pytest.param("p2p-eager", marks=pytest.mark.slow), "group-eager"])
 def test_tp2_engine_greedy_parity_on_one_gpu(tiny_ckpt, mode, monkeypatch):
     """(p2p modes: tp.init_p2p runs its full 1,000-epoch stress self-check of both hand-off flavours here.)"""
     from test_e2e_gpu import _check, _judge, _prompts, _run_ours
