@@ -113,3 +113,22 @@ def test_prefill_kernel_isa_has_none_of_the_patterns_this_project_removed():
         assert text.count("ds_bpermute_b32") <= 12, (name, "LDS round trip in the tile loop")
         assert text.count("v_accvgpr") == 0 and "scratch_" not in text, (name, "spill copies")
         assert len(re.findall(r"_store_dwordx4", text)) == 8 and not re.findall(r"_store_dwordx2", text), name
+
+
+def test_generated_prefill_loop_owns_its_register_file(kernels):
+    """attn_prefill64.hip runs ONE wave per SIMD on purpose (the whole 512-register file per lane): its generated asm loop
+    names v0 .. v191 and a0 .. a223 (tools/gen_prefill_asm.py: scores, fragment ring, O, Q, staged rows). If hipcc's own
+    code around the statement ever needed more than the 64 arch registers the clobber list leaves it, it would spill —
+    caught by the no-scratch test above; here: the kernel really takes what the stream names and not more than the file."""
+    (r,) = _named(kernels, "prefill_w64_kernel")
+    assert r.get("agpr_count", 0) >= 224 and r["vgpr_count"] <= 512, (r.get("agpr_count"), r["vgpr_count"])
+    core = open(os.path.join(ROOT, "nano_vllm_amd", "csrc", "attn_prefill64_core.inc")).read()
+    assert core.count("v_mfma_f32_32x32x16_bf16") == 32 + 4 * 64 + 2 * 32      # first tile, four step bodies, two last steps
+    # the steady-state step's budget: <= 7 instructions per MFMA outside the rare rescale path, staging, decisions and
+    # barrier included (DESIGN.md section 3; 6.3 without them: the probe's stream)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_prefill_asm as g
+    st = g.real_step(0, True, False, "t")
+    rare = 2 * (64 * 3 + 32 + 6)            # per block: accvgpr read / mul / write over 64 registers, 32 x shifts, 6 bookkeeping
+    hot = len([l for l in st.ins if not l.endswith(":")]) - rare
+    assert hot <= 7.0 * 64, hot
