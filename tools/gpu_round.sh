@@ -232,6 +232,12 @@ pmcwaits)
   # wave-cycle split of the prefill-attention kernel (same counters as profiles/r03_prefill_pmc_waits.json)
   (cd /tmp && rm -rf /tmp/pmc_pf_waits && timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CU_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU --kernel-include-regex prefill_attn -f csv -d /tmp/pmc_pf_waits -o pf -- python $REPO/tools/prefill_bench.py > $OUT/prefill_under_pmc_waits.json 2> $OUT/prefill_pmc_waits.err; echo "pmcwaits rc=$?"; tail -c 300 $OUT/prefill_pmc_waits.err)
   f=$(find /tmp/pmc_pf_waits -name '*counter_collection.csv' | head -1); [ -n "$f" ] && python tools/pmc_group_summary.py $f prefill_attn $OUT/prefill_pmc_waits.json | tail -5;;
+prefill64)
+  # the generated one-wave-per-SIMD prefill loop (attn_prefill64.hip): random packed shapes against the oracle with the shape
+  # forced, then the long-prompt shapes alternating with the 8-wave loop, then tools/prefill_bench.py's eight shapes
+  NVL_PREFILL_W64=2 timeout 900 python tools/probes/prefill_fuzz.py 60 > $OUT/prefill_fuzz_w64.log 2>&1; echo "fuzz rc=$?"; tail -1 $OUT/prefill_fuzz_w64.log
+  for w in 1 0 1 0; do NVL_PREFILL_W64=$w timeout 200 python tools/probes/prefill_time.py 2>/dev/null | tail -1 | sed "s/^/w64=$w /"; done | tee $OUT/prefill_w64_ab.txt
+  timeout 300 python tools/prefill_bench.py > $OUT/prefill_bench.json 2> $OUT/prefill_bench.err; echo "prefill bench rc=$?"; cut -c1-1600 $OUT/prefill_bench.json;;
 first8)
   # FIRST CONTACT with a multi-GPU node, unattended, most valuable evidence first (every sub-step has its own timeout; a
   # failure never stops the sequence). NGPUS=n (default: every visible GPU). FIRST8_DRY=1 = the one-GPU stand-in: 2 ranks
