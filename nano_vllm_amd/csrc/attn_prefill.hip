@@ -507,10 +507,12 @@ __global__ __launch_bounds__(NW * 64, 2) void prefill_attn_kernel(
 
 }  // namespace
 
-// attn_prefill64.hip: the 64-rows-per-wave shape (one wave per SIMD, generated asm main loop) for packed long prompts
+// attn_prefill64.hip: the 64-rows-per-wave shape (one wave per SIMD, generated asm main loop) for long bf16 prompts; returns
+// 1 when the launch does not fit it
 int nvl_prefill_w64_launch(const void* q, const void* k, const void* v, int64_t k_tok_stride, int64_t v_tok_stride,
-                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, void* out, int64_t total_q, int num_seqs,
-                           int num_q_heads, int num_kv_heads, float scale_log2e, float* lse, float rescale_thr, hipStream_t s);
+                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, const int32_t* block_tables, int64_t bt_stride,
+                           int block_size, void* out, int64_t total_q, int num_seqs, int num_q_heads, int num_kv_heads,
+                           float scale_log2e, float* lse, float rescale_thr, hipStream_t s);
 
 extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void* v, int64_t k_tok_stride,
                                        int64_t v_tok_stride, const int32_t* cu_seqlens_q,
@@ -569,11 +571,14 @@ extern "C" int nvl_attn_prefill_varlen(const void* q, const void* k, const void*
   // the one-wave-per-SIMD shape with the generated asm main loop (attn_prefill64.hip): packed K / V, long prompts (its
   // 256-row q tiles waste rows on short sequences: mean length >= 1024 as well). Measured +3 % (8 x 2048, G = 8) ... +10 %
   // (1 x 16,384) over the 8-wave loop, profiles/r06_prefill_w64_asm_*.txt
-  // (its tile offsets are 32-bit buffer offsets: the packed K / V of the launch must span < 2 GiB)
-  const bool w64_fits = total_q * (k_tok_stride > v_tok_stride ? k_tok_stride : v_tok_stride) * 2 < (1ll << 31);
-  if (w64 && ((max_seqlen_q >= 2048 && total_q >= (int64_t)num_seqs * 1024) || w64 == 2) && num_seqs <= 64 && !paged && !waves && w64_fits)
-    return nvl_prefill_w64_launch(q, k, v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, out, total_q, num_seqs,
-                                  num_q_heads, num_kv_heads, sl2, lse, thr, s);
+  // (packed: its tile offsets are 32-bit buffer offsets — the K / V of the launch must span < 2 GiB; paged: 64-bit)
+  const bool w64_fits = paged || total_q * (k_tok_stride > v_tok_stride ? k_tok_stride : v_tok_stride) * 2 < (1ll << 31);
+  if (w64 && ((max_seqlen_q >= 2048 && total_q >= (int64_t)num_seqs * 1024) || w64 == 2) && num_seqs <= 64 &&
+      kv_dtype == NVL_KV_BF16 && !waves && w64_fits) {
+    const int rc = nvl_prefill_w64_launch(q, k, v, k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables, bt_stride,
+                                          block_size, out, total_q, num_seqs, num_q_heads, num_kv_heads, sl2, lse, thr, s);
+    if (rc != 1) return rc;
+  }
   const int want = waves ? waves : (max_seqlen_q >= 2048 ? 8 : 4);
   const bool eight_ok = (num_q_heads / num_kv_heads) % 2 == 0;
   const int xcd_map = xcd_env >= 0 ? xcd_env : ((want == 4 || !eight_ok) && num_seqs <= 64 ? 1 : 0);

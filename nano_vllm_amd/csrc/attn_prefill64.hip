@@ -18,6 +18,7 @@
 #include "common.h"
 #include "attn_prefill64_core.inc"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -31,9 +32,14 @@ constexpr int kLdsBytes = 2 * kKBufB + 2 * kVBufB;
 
 typedef __attribute__((ext_vector_type(32))) float f32x32_t;
 
+// PAGED: K / V tiles come from the paged cache [block][kv head][block_size][128] through the sequence's block-table row
+// (prefix-cache hits, chunk continuations): a 64-key tile never straddles a block (block_size % 64 == 0), its byte offset
+// inside either cache is looked up once per item into an LDS table that the asm loop reads one entry per step.
+template <bool PAGED>
 __global__ __launch_bounds__(256, 1) void prefill_w64_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_tok_stride,
-    int64_t v_tok_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k, bf16_t* __restrict__ out,
+    int64_t v_tok_stride, const int32_t* __restrict__ cu_q, const int32_t* __restrict__ cu_k,
+    const int32_t* __restrict__ block_tables, int64_t bt_stride, int block_size, bf16_t* __restrict__ out,
     int num_seqs, int hq, int hkv, float scale_log2e, float* __restrict__ lse, float rescale_thr) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -64,6 +70,7 @@ __global__ __launch_bounds__(256, 1) void prefill_w64_kernel(
   int lq = __builtin_amdgcn_readlane(a1, seq) - q0;
   int k0 = __builtin_amdgcn_readlane(b0, seq);
   int lk = __builtin_amdgcn_readlane(b1, seq) - k0;
+  seq = __builtin_amdgcn_readfirstlane(seq);
   qblk = __builtin_amdgcn_readfirstlane(qblk);
   q0 = __builtin_amdgcn_readfirstlane(q0);
   lq = __builtin_amdgcn_readfirstlane(lq);
@@ -89,28 +96,48 @@ __global__ __launch_bounds__(256, 1) void prefill_w64_kernel(
 
   // ---- staging (prologue and tail; the asm loop stages its own tiles with the same addresses) ------------------------------
   const int srow = tid >> 4, sc16 = tid & 15;
-  const unsigned int koff0 = ((unsigned int)(srow * k_tok_stride) + sc16 * 8) * 2u, voff0 = ((unsigned int)(srow * v_tok_stride) + sc16 * 8) * 2u;
-  const int ktile = (int)(kKBlk * k_tok_stride * 2), vtile = (int)(kKBlk * v_tok_stride * 2);      // bytes per 64-key tile
-  const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)k0 * k_tok_stride + kvh * 128), 0,
-                                                                       (int)(lk * k_tok_stride * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)k0 * v_tok_stride + kvh * 128), 0,
-                                                                       (int)(lk * v_tok_stride * 2), 0x00020000);
+  const int64_t kstride = PAGED ? 128 : k_tok_stride, vstride = PAGED ? 128 : v_tok_stride;
+  const unsigned int koff0 = ((unsigned int)(srow * kstride) + sc16 * 8) * 2u, voff0 = ((unsigned int)(srow * vstride) + sc16 * 8) * 2u;
+  const int ktile = (int)(kKBlk * kstride * 2), vtile = (int)(kKBlk * vstride * 2);      // bytes per 64-key tile
+  // PAGED: byte offset of tile i inside either cache (tiles past the end repeat the last one: staged, never read)
+  int64_t* tab = reinterpret_cast<int64_t*>(smem + kLdsBytes);
+  auto tile_off = [&](int i) -> int64_t {
+    const int kt = min(i, nt - 1) * kKBlk;
+    const int blk = block_tables[(int64_t)seq * bt_stride + kt / block_size];
+    return ((((int64_t)blk * hkv + kvh) * block_size + (kt % block_size)) * 128) * 2;
+  };
+  if constexpr (PAGED) {
+    for (int i = tid; i < nt + 3; i += 256) tab[i] = tile_off(i);
+  }
+  __amdgpu_buffer_rsrc_t krs, vrs;
+  if constexpr (!PAGED) {
+    krs = __builtin_amdgcn_make_buffer_rsrc((void*)(k + (int64_t)k0 * k_tok_stride + kvh * 128), 0, (int)(lk * k_tok_stride * 2), 0x00020000);
+    vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(v + (int64_t)k0 * v_tok_stride + kvh * 128), 0, (int)(lk * v_tok_stride * 2), 0x00020000);
+  }
   const int kwr = srow * kKRowB + ((sc16 ^ (srow & 15)) << 4);              // chunk n: + n * 16 rows (same swizzle)
   const int vwr = 2 * kKBufB + srow * kVRowB + (sc16 << 4);
-  auto stage_k = [&](int tt, int buf) __attribute__((always_inline)) {      // rows past the end of the sequence read as zeros
+  auto stage_rows = [&](auto is_k, int tt, int buf) __attribute__((always_inline)) {   // rows past the end of the sequence read as zeros
+    constexpr bool IS_K = decltype(is_k)::value;
+    __amdgpu_buffer_rsrc_t rs;
+    int soff;
+    if constexpr (PAGED) {
+      const int64_t o = __builtin_amdgcn_readfirstlane((int)(tile_off(tt) & 0xffffffffll)) & 0xffffffffll;
+      const int64_t oh = __builtin_amdgcn_readfirstlane((int)(tile_off(tt) >> 32));
+      rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned char*)(IS_K ? k : v) + ((oh << 32) | o)), 0, kKBlk * 256, 0x00020000);
+      soff = 0;
+    } else {
+      rs = IS_K ? krs : vrs;
+      soff = tt * (IS_K ? ktile : vtile);
+    }
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
-      const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(krs, koff0 + n * (ktile >> 2), tt * ktile, 0);
-      *reinterpret_cast<u32x4_t*>(smem + buf * kKBufB + kwr + n * 16 * kKRowB) = x;
+      const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(rs, (IS_K ? koff0 : voff0) + n * ((IS_K ? ktile : vtile) >> 2), soff, 0);
+      if constexpr (IS_K) *reinterpret_cast<u32x4_t*>(smem + buf * kKBufB + kwr + n * 16 * kKRowB) = x;
+      else *reinterpret_cast<u32x4_t*>(smem + buf * kVBufB + vwr + n * 16 * kVRowB) = x;
     }
   };
-  auto stage_v = [&](int tt, int buf) __attribute__((always_inline)) {
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const u32x4_t x = __builtin_amdgcn_raw_buffer_load_b128(vrs, voff0 + n * (vtile >> 2), tt * vtile, 0);
-      *reinterpret_cast<u32x4_t*>(smem + buf * kVBufB + vwr + n * 16 * kVRowB) = x;
-    }
-  };
+  auto stage_k = [&](int tt, int buf) __attribute__((always_inline)) { stage_rows(std::true_type{}, tt, buf); };
+  auto stage_v = [&](int tt, int buf) __attribute__((always_inline)) { stage_rows(std::false_type{}, tt, buf); };
   stage_k(0, 0);
   stage_v(0, 0);
   stage_k(1, 1);
@@ -129,12 +156,25 @@ __global__ __launch_bounds__(256, 1) void prefill_w64_kernel(
     const int kma = qi_c[0] + off - 4 * hi, kmb = qi_c[1] + off - 4 * hi;
     const bf16_t* qa = q + ((int64_t)(q0 + qi_c[0]) * hq + head) * 128 + hi * 8;
     const bf16_t* qb = q + ((int64_t)(q0 + qi_c[1]) * hq + head) * 128 + hi * 8;
-    asm volatile(NVL_PF64_CORE_ASM
-                 : "={a[0:31]}"(o0), "={a[32:63]}"(o1), "={a[64:95]}"(o2), "={a[96:127]}"(o3), [ma] "=&v"(m_run[0]),
-                   [mb] "=&v"(m_run[1]), [la] "=&v"(l_run[0]), [lb] "=&v"(l_run[1])
-                 : [pk] "v"(ipk), [vl] "v"(vl), [kwr] "v"(kwr), [vwr] "v"(vwr), [kma] "v"(kma), [kmb] "v"(kmb), [kk] "v"(kk),
-                   [rb] "v"(rb), [ko] "v"(koff0), [vo] "v"(voff0), [qa] "v"(qa), [qb] "v"(qb), [ksrd] "s"(krs), [vsrd] "s"(vrs)
-                 : "memory", "vcc", "scc", NVL_PF64_CORE_CLOBBERS);
+    if constexpr (PAGED) {
+      const int ipk2 = lane == 8 ? kLdsBytes + 8 : ipk;           // LDS address of table entry 1
+      const unsigned long long kb = (unsigned long long)k, vb = (unsigned long long)v;
+      const unsigned int kb0 = (unsigned int)kb, kb1 = (unsigned int)(kb >> 32), vb0 = (unsigned int)vb, vb1 = (unsigned int)(vb >> 32);
+      asm volatile(NVL_PF64_CORE_ASM_PAGED
+                   : "={a[0:31]}"(o0), "={a[32:63]}"(o1), "={a[64:95]}"(o2), "={a[96:127]}"(o3), [ma] "=&v"(m_run[0]),
+                     [mb] "=&v"(m_run[1]), [la] "=&v"(l_run[0]), [lb] "=&v"(l_run[1])
+                   : [pk] "v"(ipk2), [vl] "v"(vl), [kwr] "v"(kwr), [vwr] "v"(vwr), [kma] "v"(kma), [kmb] "v"(kmb), [kk] "v"(kk),
+                     [rb] "v"(rb), [ko] "v"(koff0), [vo] "v"(voff0), [qa] "v"(qa), [qb] "v"(qb), [kb0] "s"(kb0), [kb1] "s"(kb1),
+                     [vb0] "s"(vb0), [vb1] "s"(vb1)
+                   : "memory", "vcc", "scc", NVL_PF64_CORE_CLOBBERS);
+    } else {
+      asm volatile(NVL_PF64_CORE_ASM
+                   : "={a[0:31]}"(o0), "={a[32:63]}"(o1), "={a[64:95]}"(o2), "={a[96:127]}"(o3), [ma] "=&v"(m_run[0]),
+                     [mb] "=&v"(m_run[1]), [la] "=&v"(l_run[0]), [lb] "=&v"(l_run[1])
+                   : [pk] "v"(ipk), [vl] "v"(vl), [kwr] "v"(kwr), [vwr] "v"(vwr), [kma] "v"(kma), [kmb] "v"(kmb), [kk] "v"(kk),
+                     [rb] "v"(rb), [ko] "v"(koff0), [vo] "v"(voff0), [qa] "v"(qa), [qb] "v"(qb), [ksrd] "s"(krs), [vsrd] "s"(vrs)
+                   : "memory", "vcc", "scc", NVL_PF64_CORE_CLOBBERS);
+    }
     t = ntw;
   } else {
     __syncthreads();              // the barrier behind the first tile (attn_prefill64_core.inc)
@@ -181,24 +221,35 @@ __global__ __launch_bounds__(256, 1) void prefill_w64_kernel(
 }  // namespace
 
 // Launch of the 64-rows-per-wave shape; arguments as validated by nvl_attn_prefill_varlen (attn_prefill.hip), which calls
-// this for packed K / V launches of <= 64 sequences with long prompts. Returns 0 / NVL_E*.
+// this for bf16 launches of <= 64 sequences with long prompts (packed K / V, or the paged cache). Returns 0 / NVL_E*, or
+// NVL_W64_DECLINED when the launch does not fit the shape (the caller takes the 8-wave loop).
 int nvl_prefill_w64_launch(const void* q, const void* k, const void* v, int64_t k_tok_stride, int64_t v_tok_stride,
-                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, void* out, int64_t total_q, int num_seqs,
-                           int num_q_heads, int num_kv_heads, float scale_log2e, float* lse, float rescale_thr, hipStream_t s) {
+                           const int32_t* cu_seqlens_q, const int32_t* cu_seqlens_k, const int32_t* block_tables, int64_t bt_stride,
+                           int block_size, void* out, int64_t total_q, int num_seqs, int num_q_heads, int num_kv_heads,
+                           float scale_log2e, float* lse, float rescale_thr, hipStream_t s) {
   const int64_t tiles = (total_q + kQRows - 1) / kQRows + num_seqs;  // upper bound on sum ceil(Lq / 256)
-  NVL_REQUIRE(tiles <= 65535 && num_seqs <= 64, "nvl_attn_prefill_varlen: too many query tiles for the 64-row shape (%lld)", (long long)tiles);
+  const bool paged = block_tables != nullptr;
+  // paged: the per-item offset table (one entry per 64-key tile a block-table row can address, + 3) rides behind the tile buffers
+  const size_t lds = kLdsBytes + (paged ? ((size_t)bt_stride * block_size / kKBlk + 3) * 8 : 0);
+  if (tiles > 65535 || num_seqs > 64 || lds > 160 * 1024) return 1;      // declined
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& done = attr_done[nvl_device_slot()];
   if (!done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_w64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes) != hipSuccess) {
-      nvl_set_error("nvl_attn_prefill_varlen: cannot reserve %d B of LDS", kLdsBytes);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_w64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&prefill_w64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+      nvl_set_error("nvl_attn_prefill_varlen: cannot reserve LDS for the 64-row shape");
       return NVL_ELAUNCH;
     }
     done = true;
   }
   dim3 grid((unsigned)num_q_heads, (unsigned)tiles);
-  hipLaunchKernelGGL(prefill_w64_kernel, grid, dim3(256), kLdsBytes, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
-                     k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, (bf16_t*)out, num_seqs, num_q_heads, num_kv_heads,
-                     scale_log2e, lse, rescale_thr);
+  if (paged)
+    hipLaunchKernelGGL(prefill_w64_kernel<true>, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables, bt_stride, block_size, (bf16_t*)out,
+                       num_seqs, num_q_heads, num_kv_heads, scale_log2e, lse, rescale_thr);
+  else
+    hipLaunchKernelGGL(prefill_w64_kernel<false>, grid, dim3(256), lds, s, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v,
+                       k_tok_stride, v_tok_stride, cu_seqlens_q, cu_seqlens_k, block_tables, bt_stride, block_size, (bf16_t*)out,
+                       num_seqs, num_q_heads, num_kv_heads, scale_log2e, lse, rescale_thr);
   return nvl_check_launch("nvl_attn_prefill_varlen");
 }

@@ -222,7 +222,10 @@ VVOFF = 181
 NEGBIG = 185
 KMAXV = (186, 187)             # per block: last visible key of this lane's row, minus 4 hi
 STG = 192                      # a[192:207] staged K rows, a[208:223] staged V rows
-SREG = dict(s_scale="s40", s_thr="s41", s_t="s42", s_ntw="s43", s_tmask="s44", s_ksoff="s45", s_vsoff="s46", s_ktile="s47",
+PAGED = False                  # set by core_include(): K / V tiles from the paged cache (a per-tile offset table in LDS)
+TABV = (201, 202, 203)          # table address, entry lo / hi
+SRD_K, SRD_V = "s[68:71]", "s[72:75]"
+SREG = dict(s_tab="s62", s_olo="s63", s_ohi="s64", s_plo="s65", s_phi="s66", s_scale="s40", s_thr="s41", s_t="s42", s_ntw="s43", s_tmask="s44", s_ksoff="s45", s_vsoff="s46", s_ktile="s47",
             s_vtile="s48", s_ktn="s49", s_m0="s[50:51]", s_m1="s[52:53]", s_m2="s[54:55]", s_tmp="s56", s_tmp2="s57")
 
 
@@ -231,6 +234,12 @@ def stage_load(st: Stream, i):
     range-checked SRDs); one request per second position of phase 1"""
     if DEL & 1:
         return
+    if PAGED:
+        if i < 4:
+            st.emit(f"buffer_load_dwordx4 {ar(STG + 4 * i, 4)}, {vr(KVOFF + i)}, {SRD_K}, 0 offen")
+        else:
+            st.emit(f"buffer_load_dwordx4 {ar(STG + 4 * i, 4)}, {vr(VVOFF + i - 4)}, {SRD_V}, 0 offen")
+        return
     if i < 4:
         st.emit(f"buffer_load_dwordx4 {ar(STG + 4 * i, 4)}, {vr(KVOFF + i)}, %[ksrd], s_ksoff offen")
     else:
@@ -238,6 +247,26 @@ def stage_load(st: Stream, i):
     if i == 7:
         st.emit("s_add_u32 s_ksoff, s_ksoff, s_ktile")
         st.emit("s_add_u32 s_vsoff, s_vsoff, s_vtile")
+
+
+def paged_lookup(st: Stream):
+    """paged cache: request the byte offset of K tile t + 2 from the LDS table (entry i = tile i's offset inside either cache)"""
+    st.emit(f"v_mov_b32 {vr(TABV[0])}, s_tab")
+    st.lds(f"ds_read_b64 {vr(TABV[1], 2)}, {vr(TABV[0])}", "tb")
+    st.emit("s_add_u32 s_tab, s_tab, 8")
+
+
+def paged_srds(st: Stream):
+    """... and turn it into the two descriptors: K tile t + 2 at the new offset, V tile t + 1 at the previous step's"""
+    st.wait_for("tb")
+    st.emit(f"v_readfirstlane_b32 s_olo, {vr(TABV[1])}")
+    st.emit(f"v_readfirstlane_b32 s_ohi, {vr(TABV[2])}")
+    st.emit("s_add_u32 s72, %[vb0], s_plo")
+    st.emit("s_addc_u32 s73, %[vb1], s_phi")
+    st.emit("s_add_u32 s68, %[kb0], s_olo")
+    st.emit("s_addc_u32 s69, %[kb1], s_ohi")
+    st.emit("s_mov_b32 s_plo, s_olo")
+    st.emit("s_mov_b32 s_phi, s_ohi")
 
 
 def stage_write(st: Stream, i, kbuf, vbuf):
@@ -338,7 +367,14 @@ def phase1_real(st: Stream, cur, nxt, kbuf_next, vbuf_cur, nxt_tile):
     for h in range(16):
         if h < NF1:
             finish_chunk(st, cur, 0, h)
-        if h % 2 == 0:
+        if PAGED:
+            if h == 1:
+                paged_srds(st)
+            if h >= 2 and h % 2 == 0:
+                stage_load(st, h // 2 - 1)
+            if h == 15:
+                stage_load(st, 7)
+        elif h % 2 == 0:
             stage_load(st, h // 2)
         if nxt_tile:
             st.wait_for(f"f{h & 3}")
@@ -401,6 +437,8 @@ def real_step(par, nxt_tile, masked, tag):
     K(t+2) -> K buffer par, V(t+1) -> V buffer par ^ 1; ends with the workgroup barrier"""
     st = Stream()
     cur, nxt = par, par ^ 1
+    if PAGED:
+        paged_lookup(st)
     if nxt_tile:
         st.emit("s_add_u32 s_ktn, s_ktn, 64")
         if masked:
@@ -415,6 +453,8 @@ def real_step(par, nxt_tile, masked, tag):
         phase1_real(st, cur, nxt, par ^ 1, par, True)
     else:
         # finish only; the V fragments 0 .. 2 are already requested
+        if PAGED:
+            paged_srds(st)
         for i in range(8):
             stage_load(st, i)
         for h in range(NF1):
@@ -466,6 +506,9 @@ def kernel_stream():
     st = Stream()
     e = st.emit
     # ---- inputs into the fixed registers -----------------------------------------------------------------------------
+    # (hipcc pads nothing in FRONT of an asm statement: its last VALU write of an input and our first v_readlane of it need
+    #  a wait state between them — found as a wrong softmax scale in the paged instantiation only)
+    e("s_nop 4")
     for i, name in enumerate(("s_scale", "s_thr", "s_ntw", "s_tmask", "s_ktile", "s_vtile", "s_ksoff", "s_vsoff")):
         e(f"v_readlane_b32 {name}, %[pk], {i}")
     e(f"v_mov_b32 {vr(VLANE)}, %[vl]")
@@ -495,6 +538,17 @@ def kernel_stream():
     e(f"v_mov_b32 {vr(L_RUN[1])}, 0")
     e("s_mov_b32 s_t, 0")
     e("s_mov_b32 s_ktn, 0")
+    if PAGED:
+        # descriptors of one cache tile each (64 rows x 256 B, range-checked); the table pointer starts at entry 1 = V(1)'s
+        # offset for step 0 (the previous step's K offset ever after)
+        e("v_readlane_b32 s_tab, %[pk], 8")
+        for base in (70, 74):
+            e(f"s_mov_b32 s{base}, 0x4000")
+            e(f"s_mov_b32 s{base + 1}, 0x00020000")
+        paged_lookup(st)
+        st.wait_for("tb")
+        e(f"v_readfirstlane_b32 s_plo, {vr(TABV[1])}")
+        e(f"v_readfirstlane_b32 s_phi, {vr(TABV[2])}")
     e("s_waitcnt vmcnt(0)")
     first_tile(st)
     st.drain()
@@ -531,19 +585,30 @@ def kernel_stream():
     return st
 
 
-def core_include():
+def core_text(paged):
+    global PAGED
+    PAGED = paged
     st = kernel_stream()
+    PAGED = False
     lines = []
     import re
     pat = re.compile(r"\b(" + "|".join(sorted(SREG, key=len, reverse=True)) + r")\b")
     for l in st.ins:
         lines.append(pat.sub(lambda m: SREG[m.group(1)], l))
     body = "\n".join(f'    "{l}\\n"' for l in lines)
-    clob = ", ".join([f'"v{i}"' for i in range(0, 192)] + [f'"a{i}"' for i in range(128, 224)] + [f'"s{i}"' for i in range(40, 62)])
+    return len(lines), body.replace(chr(10), " " + chr(92) + chr(10))
+
+
+def core_include():
+    n0, packed = core_text(False)
+    n1, paged = core_text(True)
+    clob = ", ".join([f'"v{i}"' for i in range(0, 204)] + [f'"a{i}"' for i in range(128, 224)] + [f'"s{i}"' for i in range(40, 76)])
     return f"""// GENERATED by tools/gen_prefill_asm.py — do not edit; the generator's docstring describes the schedule.
-// {len(lines)} instructions (two plain steps, two masked steps, two last steps, prologue).
+// Packed K / V: {n0} instructions, paged cache: {n1} (two plain steps, two masked steps, two last steps, prologue, each).
 #define NVL_PF64_CORE_ASM \\
-{body.replace(chr(10), " " + chr(92) + chr(10))}
+{packed}
+#define NVL_PF64_CORE_ASM_PAGED \\
+{paged}
 #define NVL_PF64_CORE_CLOBBERS {clob}
 """
 

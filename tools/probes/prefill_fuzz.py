@@ -1,11 +1,14 @@
-"""Random-shape comparison of nvl_attn_prefill_varlen (packed K / V) with the CPU oracle: python tools/probes/prefill_fuzz.py [n]
+"""Random-shape comparison of nvl_attn_prefill_varlen with the CPU oracle: python tools/probes/prefill_fuzz.py [n] [--paged]
+(packed K / V, or — --paged — a paged cache with shuffled block tables and Lq <= Lk: prefix-cache hits / chunk continuations).
 Run with NVL_PREFILL_W64=2 to put every case on the generated one-wave-per-SIMD loop. Prints one line per case, fails loudly."""
 import os, random, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nano_vllm_amd import ops
 from oracle import ops as ref
 ops.load_library()
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n = int(args[0]) if args else 40
+paged = "--paged" in sys.argv
 rnd = random.Random(1234)
 worst = 0.0
 for case in range(n):
@@ -24,9 +27,27 @@ for case in range(n):
         k[i // 2, 0] = (q[i, 0].float() * rnd.choice([0.5, 3.0])).to(torch.bfloat16)
     cu = torch.tensor([0] + torch.tensor(lens).cumsum(0).tolist(), dtype=torch.int32)
     scale = 128 ** -0.5
-    o_ref, lse_ref = ref.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, scale, True, None, return_softmax_lse=True)
     lse = torch.zeros(tot, hq, dtype=torch.float32, device="cuda")
-    o = ops.attn_prefill_varlen(q.cuda(), k.cuda(), v.cuda(), cu.cuda(), cu.cuda(), max(lens), scale, lse=lse)
+    if paged:
+        bs = rnd.choice([256, 512])
+        lks = [l + rnd.choice([0, 1, 64, 255, 256, 700, 2048]) for l in lens]          # cached prefix in front of every prompt
+        nb_each = [(x + bs - 1) // bs for x in lks]
+        total = sum(nb_each) + 3
+        perm = torch.randperm(total, generator=gen).tolist()
+        bt = torch.full((nseq, max(nb_each)), -1, dtype=torch.int32)
+        kc = torch.randn(total, bs, hkv, 128, generator=gen).to(torch.bfloat16)
+        vc = torch.randn(total, bs, hkv, 128, generator=gen).to(torch.bfloat16)
+        it = iter(perm)
+        for si, nb in enumerate(nb_each):
+            for j in range(nb):
+                bt[si, j] = next(it)
+        cuk = torch.tensor([0] + torch.tensor(lks).cumsum(0).tolist(), dtype=torch.int32)
+        o_ref, lse_ref = ref.flash_attn_varlen_func(q, kc, vc, max(lens), cu, max(lks), cuk, scale, True, bt, return_softmax_lse=True)
+        o = ops.attn_prefill_varlen(q.cuda(), ref.to_head_major(kc).cuda(), ref.to_head_major(vc).cuda(), cu.cuda(), cuk.cuda(),
+                                    max(lens), scale, block_tables=bt.cuda(), lse=lse)
+    else:
+        o_ref, lse_ref = ref.flash_attn_varlen_func(q, k, v, max(lens), cu, max(lens), cu, scale, True, None, return_softmax_lse=True)
+        o = ops.attn_prefill_varlen(q.cuda(), k.cuda(), v.cuda(), cu.cuda(), cu.cuda(), max(lens), scale, lse=lse)
     err = (o.cpu().float() - o_ref.float()).abs().max().item() / (o_ref.float().abs().max().item() + 1e-9)
     lerr = float((lse.cpu() - lse_ref).abs().max())
     worst = max(worst, err)
