@@ -1,5 +1,5 @@
 // The long-prompt shape of the varlen causal GQA prefill attention (flash_attn_varlen_func, nano-vllm
-// layers/attention.py:64-70; packed K / V): ONE wave per SIMD, 64 query rows per wave, and a main loop that is ONE
+// layers/attention.py:64-70; packed K / V or the paged cache, bf16): ONE wave per SIMD, 64 query rows per wave, and a main loop that is ONE
 // generated asm statement (attn_prefill64_core.inc, tools/gen_prefill_asm.py): every register fixed, every lgkmcnt counted,
 // 6.3 instructions per MFMA.
 //

@@ -236,6 +236,8 @@ prefill64)
   # the generated one-wave-per-SIMD prefill loop (attn_prefill64.hip): random packed shapes against the oracle with the shape
   # forced, then the long-prompt shapes alternating with the 8-wave loop, then tools/prefill_bench.py's eight shapes
   NVL_PREFILL_W64=2 timeout 900 python tools/probes/prefill_fuzz.py 60 > $OUT/prefill_fuzz_w64.log 2>&1; echo "fuzz rc=$?"; tail -1 $OUT/prefill_fuzz_w64.log
+  NVL_PREFILL_W64=2 timeout 900 python tools/probes/prefill_fuzz.py 40 --paged > $OUT/prefill_fuzz_w64_paged.log 2>&1; echo "paged fuzz rc=$?"; tail -1 $OUT/prefill_fuzz_w64_paged.log
+  for w in 1 0; do NVL_PREFILL_W64=$w timeout 200 python tools/probes/prefill_time_paged.py 2>/dev/null | tail -1 | sed "s/^/paged w64=$w /"; done | tee $OUT/prefill_w64_paged_ab.txt
   for w in 1 0 1 0; do NVL_PREFILL_W64=$w timeout 200 python tools/probes/prefill_time.py 2>/dev/null | tail -1 | sed "s/^/w64=$w /"; done | tee $OUT/prefill_w64_ab.txt
   timeout 300 python tools/prefill_bench.py > $OUT/prefill_bench.json 2> $OUT/prefill_bench.err; echo "prefill bench rc=$?"; cut -c1-1600 $OUT/prefill_bench.json;;
 first8)
