@@ -120,10 +120,12 @@ def test_generated_prefill_loop_owns_its_register_file(kernels):
     names v0 .. v191 and a0 .. a223 (tools/gen_prefill_asm.py: scores, fragment ring, O, Q, staged rows). If hipcc's own
     code around the statement ever needed more than the 64 arch registers the clobber list leaves it, it would spill —
     caught by the no-scratch test above; here: the kernel really takes what the stream names and not more than the file."""
-    (r,) = _named(kernels, "prefill_w64_kernel")
-    assert r.get("agpr_count", 0) >= 224 and r["vgpr_count"] <= 512, (r.get("agpr_count"), r["vgpr_count"])
+    rows = _named(kernels, "prefill_w64_kernel")
+    assert len(rows) == 2                                                       # packed K / V, paged cache
+    for r in rows:
+        assert r.get("agpr_count", 0) >= 224 and r["vgpr_count"] <= 512, (r.get("agpr_count"), r["vgpr_count"])
     core = open(os.path.join(ROOT, "nano_vllm_amd", "csrc", "attn_prefill64_core.inc")).read()
-    assert core.count("v_mfma_f32_32x32x16_bf16") == 32 + 4 * 64 + 2 * 32      # first tile, four step bodies, two last steps
+    assert core.count("v_mfma_f32_32x32x16_bf16") == 2 * (32 + 4 * 64 + 2 * 32)  # per stream: first tile, four step bodies, two last steps
     # the steady-state step's budget: <= 7 instructions per MFMA outside the rare rescale path, staging, decisions and
     # barrier included (DESIGN.md section 3; 6.3 without them: the probe's stream)
     sys.path.insert(0, os.path.join(ROOT, "tools"))
