@@ -751,9 +751,11 @@ def prefill_replay(torch, runner, batches) -> dict:
     dev = runner.device
     start, stop = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     flops, ms, launches = 0.0, 0.0, 0
+    w64 = 0                 # batches the launcher hands to the generated one-wave-per-SIMD loop (attn_prefill.hip's rule)
     for cu in batches:
         n = int(cu[-1])
         lens = (cu[1:] - cu[:-1]).astype("int64")
+        w64 += int(os.environ.get("NVL_PREFILL_W64", "1") != "0" and len(lens) <= 64 and lens.max() >= 2048 and n >= 1024 * len(lens))
         q = torch.randn(n, hq, 128, device=dev, dtype=torch.bfloat16)
         k = torch.randn(n, hkv, 128, device=dev, dtype=torch.bfloat16)
         v = torch.randn(n, hkv, 128, device=dev, dtype=torch.bfloat16)
@@ -770,7 +772,10 @@ def prefill_replay(torch, runner, batches) -> dict:
         flops += 4 * 4.0 * hq * 128 * float((lens * (lens + 1) // 2).sum())
     achieved = flops / (ms * 1e-3) / 1e12
     return {"bound": "mfma", "achieved": achieved, "peak": 2500.0, "unit": "TFLOP/s", "frac": achieved / 2500.0,
-            "traffic": None, "kernel": "prefill_attn_kernel<false> (nvl_attn_prefill_varlen)",
+            "traffic": None,
+            "kernel": ("prefill_w64_kernel<false>, the generated asm loop" if w64 == len(batches) and w64 else
+                       "prefill_attn_kernel<false>" if not w64 else "prefill_attn_kernel<false> / prefill_w64_kernel<false>") +
+                      " (nvl_attn_prefill_varlen)",
             "avg_launch_us": ms * 1e3 / launches, "launches_timed": launches}
 
 
