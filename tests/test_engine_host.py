@@ -543,15 +543,15 @@ def test_bench_line_stays_compact(monkeypatch, tmp_path):
     # an exhausted wall budget skips the remaining extras and says so
     monkeypatch.setattr(bench, "BENCH_T0", __import__("time").perf_counter() - 10_000)
     assert all("skipped" in v["error"] for v in bench.extra_configs(args, fake_torch).values())
-    # an extra is never STARTED with less of the 255 s budget left than it is known to need (the driver's 20 + 5 passes
-    # leave ~100 s: BASELINE's own configs come first, then the rank shapes). Fake children take no time: with 35 s
+    # an extra is never STARTED with less of the 262 s budget left than it is known to need (the driver's 20 + 5 passes
+    # leave ~100 s: BASELINE's own configs come first, then the rank shapes). Fake children take no time: with 42 s
     # left, the 48 s and 44 s ones are skipped and say so, the others run
     monkeypatch.setattr(bench, "BENCH_T0", __import__("time").perf_counter() - 220)
     ex = bench.extra_configs(args, fake_torch)
     assert list(ex) == ["config3", "config4_anchor", "config5", "tp8_rank_shape_bench", "tp4_rank_shape_bench",
                         "tp8_rank_shape_16k_prompts"]
     assert [k for k, v in ex.items() if "error" in v] == ["config4_anchor", "tp8_rank_shape_16k_prompts"]
-    assert "needs ~48 s" in ex["config4_anchor"]["error"] and "255 s wall budget" in ex["config4_anchor"]["error"]
+    assert "needs ~48 s" in ex["config4_anchor"]["error"] and "262 s wall budget" in ex["config4_anchor"]["error"]
     assert len(_json.dumps(bench.NOTES)) < 6000 and bench.write_notes({}).startswith("gpurun_out/")
 
 
