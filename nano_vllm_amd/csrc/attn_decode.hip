@@ -1114,16 +1114,14 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
   // batch = two groups). A pack is served once per group that has a live member in it — one workgroup (blockIdx.y) per group,
   // that group's tiles with the other rows as zero columns; almost every pack holds one group. `present`: bit g = group g has
   // a live member here.
-  // (one vector round trip for the pack's <= 16 context lengths and group ids — lane j holds sequence b0 + j — instead of 2 P
-  //  dependent scalar loads in front of everything else this workgroup does: the pass is a latency chain, not bytes)
-  int ctx_j = 0, grp_j = 0;
-  if (lane < P && b0 + lane < batch) {
-    ctx_j = ctx[b0 + lane];
-    grp_j = member[b0 + lane];
-  }
-  const unsigned bit_j = (ctx_j > 0 && grp_j > 0 && grp_j < 32) ? 1u << grp_j : 0u;
   unsigned present = 0;
-  for (int j = 0; j < P; ++j) present |= (unsigned)__builtin_amdgcn_readlane((int)bit_j, j);
+  for (int j = 0; j < P; ++j) {
+    const int bj = b0 + j;
+    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0) {
+      const int gm = __builtin_amdgcn_readfirstlane(member[bj]);
+      if (gm > 0 && gm < 32) present |= 1u << gm;
+    }
+  }
   // blockIdx.y = which of the pack's groups this workgroup serves (the launch has as many y slots as the plan was built for:
   // 1 unless the engine found several groups); fewer groups in the pack than slots: nothing to do
   int gid = 0;
@@ -1146,8 +1144,11 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
   constexpr int kTL = KV8 ? kLoads8 : kLoads;
   u32x4_t kd[kTL], vd[kTL];
   // the block-table row the prefix tiles are looked up in: the pack's first live member of this group (all of them agree)
-  const unsigned long long mine_m = __ballot(ctx_j > 0 && grp_j == gid);          // (gid > 0 here: lanes >= P hold group 0)
-  const int tb = __builtin_amdgcn_readfirstlane(b0 + (int)__builtin_ctzll(mine_m));
+  int tb = -1;
+  for (int j = P - 1; j >= 0; --j) {
+    const int bj = b0 + j;
+    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0 && __builtin_amdgcn_readfirstlane(member[bj]) == gid) tb = bj;
+  }
   auto tile_block = [&](int ti) { return block_tables[(int64_t)tb * bt_stride + (ti * kTile) / block_size]; };
   auto tile_load = [&](int blk, int ti) {
     const int t = ti * kTile;
