@@ -535,6 +535,9 @@ def run_replica(args, torch, dist, rank, world, tp, backend):
     path = os.path.join(tempfile.gettempdir(), f"nvl_{args.model}_r{rank}")
     write_synthetic_checkpoint(path, args.model, with_weights=False, vocab_size=MODEL_VOCAB.get(args.model, 151936))
     llm = LLM(path, **engine_kwargs(args, tp))
+    if rank == 0:       # which build of the library this run measures (NVL_LIBDIR selects another one for A/B runs)
+        from nano_vllm_amd import ops as _ops
+        print(f"[bench.py] library: {_ops.LIB_PATH}", file=sys.stderr, flush=True)
 
     # ---- record decode batches of a pass (for the roofline replay) --------------------------
     runner = llm.model_runner
@@ -727,7 +730,8 @@ def roofline_replay(torch, runner, rec, model: str = "qwen3-0.6b") -> dict:
         kernel = f"decode_stream_fp8_kernel<{G}, fused>" if fp8 else f"decode_stream_kernel<{G}, fused>"
     step_bytes = (rec["ctx_tokens"] - rec.get("dedup_tokens", 0)) * 2 * hkv * 128 * runner.kv_cache.element_size() * L
     if r["launches_with_shared_prefix_pass"]:
-        kernel = "decode_prefix_kernel + " + kernel
+        # (one launch: the stream-K grid + the workgroups that serve the shared-prefix packs, attn_decode.hip)
+        kernel = kernel.replace("decode_mfma8_kernel", "decode_mfma8_shared_kernel")
     extra = {}
     if r["launches_with_shared_prefix_pass"]:
         # the reference's attention reads the shared blocks once per sequence; the bytes credited here are the unique ones

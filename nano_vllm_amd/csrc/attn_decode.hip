@@ -705,12 +705,15 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 // KV8: the cache holds OCP fp8 e4m3 rows of 128 bytes (opt-in, see decode_stream_fp8_kernel): a tile is loaded as
 // 8 rows x 16 elements per wave instruction and converted (exactly) to bf16 on its way into the wave's LDS tile; the
 // new token's k / v are quantised before they enter this step's softmax. Everything after the LDS write is unchanged.
-template <bool FUSED, bool KV8, int G = 8, bool SLABS = false>
-__global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
+// (the body is a device function of (workgroup index, workgroups of the stream-K grid): the plain kernel runs it on every
+//  workgroup, decode_mfma8_shared_kernel on the first `main_blocks` of a launch whose remaining workgroups serve the
+//  shared-prefix packs)
+template <bool FUSED, bool KV8, int G, bool SLABS>
+__device__ __forceinline__ void mfma8_body(
     const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
     int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
     int* __restrict__ meta, bf16_t* __restrict__ out, int batch, int hkv, int block_size, int slots,
-    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan, int g_rt) {
+    float scale_log2e, const FusedArgs& fa, const PlanHeader* __restrict__ plan, int g_rt, const int block, const int nblocks) {
   // G = 0: the group size is the runtime argument g_rt (1 ... 16; Qwen3-14B is 40 / 8 = 5) — one instantiation serves every
   // group size without a tuned one; the heads still fill ONE 16-column MFMA tile, padded with zero columns
   static_assert(G >= 0 && G <= 16, "one 16-column MFMA tile holds the heads of a kv group (padded with zero columns)");
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   unsigned char* k_lds = smem_raw + wave * kMWaveLds;
   unsigned char* v_lds = k_lds + kTile * kMKRow;
 
-  const int64_t wid = (int64_t)blockIdx.x * kWaves + wave;
+  const int64_t wid = (int64_t)block * kWaves + wave;
   int64_t total, per;
   int sh = 0;                // leading tiles of every MEMBER sequence that belong to the shared-prefix pass (plan only)
   const int32_t* member = nullptr;
@@ -743,7 +746,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     // A plan is only valid for the (batch, Hkv, grid) it was built for. The host side refuses a mismatch
     // (plan_shadow_check); should one reach the device anyway — a replayed graph whose plan buffer was overwritten by a
     // differently shaped nvl_decode_plan — the launch does NO work instead of indexing past the records.
-    const bool plan_ok = plan->nwaves == (int)(gridDim.x * kWaves) && plan->batch == batch && plan->hkv == hkv;
+    const bool plan_ok = plan->nwaves == (int)(nblocks * kWaves) && plan->batch == batch && plan->hkv == hkv;
     total = plan_ok ? plan->total : 0;
     per = plan->per;
     sh = plan->sh_tiles;
@@ -753,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
     chunk_prefix(ctx, batch, kTile, pre, wsum);
     __syncthreads();
     total = (int64_t)pre[batch] * hkv;
-    const int64_t nwaves = (int64_t)gridDim.x * kWaves;
+    const int64_t nwaves = (int64_t)nblocks * kWaves;
     per = (total + nwaves - 1) / nwaves;
     if (per < kMinTilesPerWave) per = kMinTilesPerWave;
   }
@@ -1076,6 +1079,16 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
   }
 }
 
+template <bool FUSED, bool KV8, int G = 8, bool SLABS = false>
+__global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
+    const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
+    int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
+    int* __restrict__ meta, bf16_t* __restrict__ out, int batch, int hkv, int block_size, int slots,
+    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan, int g_rt) {
+  mfma8_body<FUSED, KV8, G, SLABS>(q, kc, vc, block_tables, bt_stride, ctx, part_o, part_ml, meta, out, batch, hkv, block_size,
+                                   slots, scale_log2e, fa, plan, g_rt, (int)blockIdx.x, (int)gridDim.x);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Shared-prefix pass (plans built with `shared_prefix`, nvl_decode_plan). When the MEMBER sequences of a step start
 // with the same `sh` tiles of KV (prefix-cache hits on one system prompt — BASELINE config 3: 256 sequences x a
@@ -1089,12 +1102,19 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
 // decode_stream_combine_kernel folds it in. The stream-K kernel itself starts every member at tile `sh` (PlanHeader).
 // The new token's q is needed here as well: FUSED recomputes norm + rotation from the raw qkv row (bit-identical to the
 // stream-K kernel's, same helpers); K / V of the new token are the stream-K kernel's business alone.
+//
+// Round 6, last form: the pass is NOT a launch of its own any more. The packs are served by the LAST `nblocks` workgroups of
+// the stream-K launch itself (decode_mfma8_shared_kernel; the plan's stream-K grid is that much smaller), each of them walking
+// over its share of the (group slot, pack, kv head) items: the ~19 us latency chain of the separate launch (launch boundary,
+// header -> lengths -> block table -> first tile, LDS merge) now runs UNDER the HBM-bound stream-K shares instead of in front of
+// them, on the same CUs.
 template <bool FUSED, bool KV8, int G, bool SLABS>
-__global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
+__device__ __forceinline__ void prefix_body(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
     const int32_t* __restrict__ block_tables, int64_t bt_stride, const int32_t* __restrict__ ctx,
     float* __restrict__ part_o, float* __restrict__ part_ml, int batch, int hkv, int block_size, int slots,
-    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan, int g_rt) {
+    float scale_log2e, const FusedArgs& fa, const PlanHeader* __restrict__ plan, int g_rt, const int block, const int nblocks,
+    const int group_slots) {
   // a pack fills the 16 MFMA columns with P = floor(16 / G) sequences; columns P G .. 15 (group sizes that do not divide 16)
   // are zero padding. G = 0: runtime group size g_rt, as in decode_mfma8_kernel
   static_assert(G >= 0 && G <= 16, "a pack fills the 16 MFMA columns with floor(16 / G) sequences");
@@ -1108,52 +1128,67 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
   const int sub = lane & 15, rq = lane >> 4;      // prologue view: 16 lanes x 8 dims = one row
   const int col = lane & 15, quad = lane >> 4;    // MFMA view: one (sequence, head) column per lane
   const int hq = hkv * Gv;
-  const int pack = blockIdx.x / hkv, h = blockIdx.x - pack * hkv;
-  const int b0 = pack * P;
-  // Member flags are GROUP ids (round 6): rows with the same id > 0 start with the same `sh` tiles (two system prompts in one
-  // batch = two groups). A pack is served once per group that has a live member in it — one workgroup (blockIdx.y) per group,
-  // that group's tiles with the other rows as zero columns; almost every pack holds one group. `present`: bit g = group g has
-  // a live member here.
-  unsigned present = 0;
-  for (int j = 0; j < P; ++j) {
-    const int bj = b0 + j;
-    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0) {
-      const int gm = __builtin_amdgcn_readfirstlane(member[bj]);
-      if (gm > 0 && gm < 32) present |= 1u << gm;
-    }
-  }
-  // blockIdx.y = which of the pack's groups this workgroup serves (the launch has as many y slots as the plan was built for:
-  // 1 unless the engine found several groups); fewer groups in the pack than slots: nothing to do
-  int gid = 0;
-  {
-    unsigned rest = present;
-    for (int sidx = 0; rest != 0; ++sidx) {
-      const int low = __builtin_ctz(rest);
-      if (sidx == (int)blockIdx.y) { gid = low; break; }
-      rest &= rest - 1;
-    }
-  }
-  if (gid == 0) return;                                                     // a pack of graph padding / of non-members
   unsigned char* k_lds = smem_raw + wave * kMWaveLds;
   unsigned char* v_lds = k_lds + kTile * kMKRow;
   int kfrag[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) kfrag[c] = col * kMKRow + (((4 * c + quad) ^ col) << 4);
   const int vfrag = (4 * quad + (col >> 2)) * kMVRow + (col & 3) * 8;
-
+  // items: (group slot, pack, kv head), slot-major — a workgroup takes items block, block + nblocks, ...
+  // The walk is SOFTWARE-PIPELINED: beside the HBM-bound stream-K workgroups of the same CU a dependent round trip costs several
+  // microseconds, and an item is a chain of them (lengths / group ids -> block table -> tiles -> merge). So the lengths and group
+  // ids of the NEXT item are requested while the current one is computed, the next item's first tile is requested
+  // before the current item's merge, and the prologue takes a row's length from the pack's header by a
+  // lane shuffle instead of loading it again.
+  const int per_slot = ((batch + P - 1) / P) * hkv;
+  const int n_items = per_slot * group_slots;
+  const int t_begin = (wave * sh) / kWaves, t_end = ((wave + 1) * sh) / kWaves;       // this wave's quarter of the prefix
   constexpr int kTL = KV8 ? kLoads8 : kLoads;
-  u32x4_t kd[kTL], vd[kTL];
-  // the block-table row the prefix tiles are looked up in: the pack's first live member of this group (all of them agree)
-  int tb = -1;
-  for (int j = P - 1; j >= 0; --j) {
-    const int bj = b0 + j;
-    if (bj < batch && __builtin_amdgcn_readfirstlane(ctx[bj]) > 0 && __builtin_amdgcn_readfirstlane(member[bj]) == gid) tb = bj;
-  }
-  auto tile_block = [&](int ti) { return block_tables[(int64_t)tb * bt_stride + (ti * kTile) / block_size]; };
-  auto tile_load = [&](int blk, int ti) {
+  u32x4_t kdA[kTL], vdA[kTL];
+  struct Item { int b0, h, gid, tb; };          // (wave-uniform)
+  // lane j < P of the header holds (context length, group id) of sequence b0 + j
+  auto hdr_load = [&](int item, int& c, int& g) {
+    const int pitem = item % per_slot;
+    const int bj = (pitem / hkv) * P + lane;
+    c = 0; g = 0;
+    if (item < n_items && lane < P && bj < batch) {
+      c = ctx[bj];
+      g = member[bj];
+    }
+  };
+  // Member flags are GROUP ids: rows with the same id > 0 start with the same `sh` tiles (two system prompts in one batch = two
+  // groups). A pack is served once per group that has a live member in it — one item (slot) per group, that group's tiles with
+  // the other rows as zero columns; almost every pack holds one group. gid == 0: nothing to do (graph padding, non-members, or
+  // fewer groups in the pack than slots)
+  auto resolve = [&](int item, int c, int g) {
+    Item it = {0, 0, 0, 0};
+    if (item >= n_items) return it;
+    const int slot_y = item / per_slot;
+    const int pitem = item - slot_y * per_slot;
+    const int pack = pitem / hkv;
+    it.h = pitem - pack * hkv;
+    it.b0 = pack * P;
+    const unsigned bit_j = (c > 0 && g > 0 && g < 32) ? 1u << g : 0u;
+    unsigned present = 0;
+    for (int j = 0; j < P; ++j) present |= (unsigned)__builtin_amdgcn_readlane((int)bit_j, j);
+    unsigned rest = present;
+    for (int sidx = 0; rest != 0; ++sidx) {
+      const int low = __builtin_ctz(rest);
+      if (sidx == slot_y) { it.gid = low; break; }
+      rest &= rest - 1;
+    }
+    if (it.gid != 0) {
+      // the block-table row the prefix tiles are looked up in: the pack's first live member of this group (all of them agree)
+      const unsigned long long mine_m = __ballot(c > 0 && g == it.gid);
+      it.tb = __builtin_amdgcn_readfirstlane(it.b0 + (int)__builtin_ctzll(mine_m));
+    }
+    return it;
+  };
+  auto tile_block = [&](const Item& it, int ti) { return block_tables[(int64_t)it.tb * bt_stride + (ti * kTile) / block_size]; };
+  auto tile_load = [&](u32x4_t (&kd)[kTL], u32x4_t (&vd)[kTL], const Item& it, int blk, int ti) {
     const int t = ti * kTile;
     if constexpr (KV8) {
-      const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
+      const int64_t base = (((int64_t)blk * hkv + it.h) * block_size + (t % block_size)) * 128 + lane * 16;   // bytes
       const unsigned char* kp = reinterpret_cast<const unsigned char*>(kc) + base;
       const unsigned char* vp = reinterpret_cast<const unsigned char*>(vc) + base;
 #pragma unroll
@@ -1161,7 +1196,7 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
 #pragma unroll
       for (int i = 0; i < kLoads8; ++i) vd[i] = *reinterpret_cast<const u32x4_t*>(vp + i * 8 * 128);
     } else {
-      const int64_t base = (((int64_t)blk * hkv + h) * block_size + (t % block_size)) * 128 + lane * 8;
+      const int64_t base = (((int64_t)blk * hkv + it.h) * block_size + (t % block_size)) * 128 + lane * 8;
       const bf16_t* kp = kc + base;
       const bf16_t* vp = vc + base;
 #pragma unroll
@@ -1170,170 +1205,216 @@ __global__ __launch_bounds__(256, 2) void decode_prefix_kernel(
       for (int i = 0; i < kLoads; ++i) vd[i] = *reinterpret_cast<const u32x4_t*>(vp + i * 4 * 128);
     }
   };
+  // the first tile of this wave's quarter (through L2 on purpose: the other packs read the same tiles)
+  auto first_tiles = [&](const Item& it) {
+    if (it.gid == 0) return;
+    if (t_begin < t_end) tile_load(kdA, vdA, it, tile_block(it, t_begin), t_begin);
+  };
 
-  // this wave's quarter of the prefix; its first tile is requested BEFORE the q prologue (the two are independent: the
-  // prologue's own loads — context length, rotation table row, qkv row — are a chain of L2 round trips of their own)
-  const int t_begin = (wave * sh) / kWaves, t_end = ((wave + 1) * sh) / kWaves;
-  if (t_begin < t_end) tile_load(tile_block(t_begin), t_begin);
-  __builtin_amdgcn_sched_barrier(0);
-
-  // ---- q tile [16 columns][128]: column r = (sequence b0 + r / G, head h G + r % G); rows of dead sequences are zero ----
-  {
-    u32x4_t wq = {0u, 0u, 0u, 0u};
-    if constexpr (FUSED) {
-      if (fa.q_norm_w != nullptr) wq = *reinterpret_cast<const u32x4_t*>(fa.q_norm_w + sub * 8);
-    }
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = rq + 4 * it;
-      const int seq = b0 + r / Gv, hd = r % Gv;
-      const int seq_c = seq < batch ? seq : batch - 1;
-      const int len = ctx[seq_c];
-      const bool live = r < P * Gv && seq < batch && len > 0 && member[seq_c] == gid;
-      u32x4_t qh;
-      if constexpr (FUSED) {
-        int64_t pos = len > 0 ? len - 1 : 0;
-        pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
-        const RopeRegs rr = load_rope_regs(fa.cos_sin + pos * 128, sub);
-        qh = load_qkv8<SLABS>(q, (int64_t)seq_c * fa.qkv_tok_stride + (h * Gv + hd) * 128 + sub * 8, fa);
-        qh = norm_rope_head_regs(qh, fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
-      } else {
-        qh = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)seq_c * hq + h * Gv + hd) * 128 + sub * 8);
-      }
-      if (!live) qh = u32x4_t{0u, 0u, 0u, 0u};
-      *reinterpret_cast<u32x4_t*>(k_lds + r * 256 + sub * 16) = qh;
-    }
-  }
-  bf16x8_t qb[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    qb[c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(k_lds + col * 256 + (4 * c + quad) * 16));
-
-  float m_run = kNegBig, l_run = 0.f;
-  f32x4_t oacc[8];
-#pragma unroll
-  for (int db = 0; db < 8; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-  for (int ti = t_begin; ti < t_end; ++ti) {
-    const bool has_pf = ti + 1 < t_end;
-    const int pf_blk = has_pf ? tile_block(ti + 1) : 0;
-    if constexpr (KV8) {
-      const int r8 = lane >> 3, c0 = (lane & 7) * 2;
-#pragma unroll
-      for (int i = 0; i < kLoads8; ++i) {
-        const int rowi = i * 8 + r8;
-        u32x4_t lo16, hi16;
-        fp8x16_to_bf16(kd[i], &lo16, &hi16);
-        *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((c0 ^ (rowi & 15)) << 4)) = lo16;
-        *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + (((c0 + 1) ^ (rowi & 15)) << 4)) = hi16;
-      }
-#pragma unroll
-      for (int i = 0; i < kLoads8; ++i) {
-        const int rowi = i * 8 + r8;
-        u32x4_t lo16, hi16;
-        fp8x16_to_bf16(vd[i], &lo16, &hi16);
-        *reinterpret_cast<u32x4_t*>(v_lds + rowi * kMVRow + c0 * 16) = lo16;
-        *reinterpret_cast<u32x4_t*>(v_lds + rowi * kMVRow + (c0 + 1) * 16) = hi16;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < kLoads; ++i) {
-        const int rowi = i * 4 + rq;
-        *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((sub ^ (rowi & 15)) << 4)) = kd[i];
-      }
-#pragma unroll
-      for (int i = 0; i < kLoads; ++i)
-        *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
-    }
+  int ctx_j, grp_j, ctx_n, grp_n;
+  hdr_load(block, ctx_j, grp_j);
+  hdr_load(block + nblocks, ctx_n, grp_n);
+  Item cur = resolve(block, ctx_j, grp_j);
+  first_tiles(cur);
+  for (int item = block; item < n_items; item += nblocks) {
     __builtin_amdgcn_sched_barrier(0);
-    if (has_pf) tile_load(pf_blk, ti + 1);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- S^T, online softmax (every prefix token precedes every live sequence's new token: no masking), O^T ----
-    f32x4_t sacc[2];
+    const int gid = cur.gid, h = cur.h, b0 = cur.b0;
+    float m_run = kNegBig, l_run = 0.f;
+    f32x4_t oacc[8];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf) {
-      sacc[hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int db = 0; db < 8; ++db) oacc[db] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    if (gid != 0) {
+      // ---- q tile [16 columns][128]: column r = (sequence b0 + r / G, head h G + r % G); rows of dead sequences are zero ----
+      {
+        u32x4_t wq = {0u, 0u, 0u, 0u};
+        if constexpr (FUSED) {
+          if (fa.q_norm_w != nullptr) wq = *reinterpret_cast<const u32x4_t*>(fa.q_norm_w + sub * 8);
+        }
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const u32x4_t a = *reinterpret_cast<const u32x4_t*>(k_lds + hf * 16 * kMKRow + kfrag[c]);
-        sacc[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qb[c], sacc[hf], 0, 0, 0);
+        for (int it = 0; it < 4; ++it) {
+          const int r = rq + 4 * it;
+          const int sj = r / Gv, hd = r % Gv;
+          const int seq = b0 + sj;
+          const int seq_c = seq < batch ? seq : batch - 1;
+          const int len = __shfl(ctx_j, sj < P ? sj : 0, 64);             // (lane sj of the header; lanes >= P hold 0)
+          const int grp = __shfl(grp_j, sj < P ? sj : 0, 64);
+          const bool live = r < P * Gv && seq < batch && len > 0 && grp == gid;
+          u32x4_t qh;
+          if constexpr (FUSED) {
+            int64_t pos = len > 0 ? len - 1 : 0;
+            pos = pos >= fa.max_pos ? fa.max_pos - 1 : pos;
+            const RopeRegs rr = load_rope_regs(fa.cos_sin + pos * 128, sub);
+            qh = load_qkv8<SLABS>(q, (int64_t)seq_c * fa.qkv_tok_stride + (h * Gv + hd) * 128 + sub * 8, fa);
+            qh = norm_rope_head_regs(qh, fa.q_norm_w != nullptr, wq, fa.eps, rr, sub);
+          } else {
+            qh = *reinterpret_cast<const u32x4_t*>(q + ((int64_t)seq_c * hq + h * Gv + hd) * 128 + sub * 8);
+          }
+          if (!live) qh = u32x4_t{0u, 0u, 0u, 0u};
+          *reinterpret_cast<u32x4_t*>(k_lds + r * 256 + sub * 16) = qh;
+        }
       }
-    }
-    float mx = kNegBig;
+      bf16x8_t qb[4];
 #pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        sacc[hf][rr] *= scale_log2e;
-        mx = fmaxf(mx, sacc[hf][rr]);
-      }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - mn);
-    m_run = mn;
-    float psum = 0.f;
-    bf16x8_t pb;
-#pragma unroll
-    for (int hf = 0; hf < 2; ++hf)
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const float pv = exp2f(sacc[hf][rr] - mn);
-        psum += pv;
-        pb[hf * 4 + rr] = (bf16_t)pv;
-      }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 8; ++db) oacc[db] *= alpha;
-#pragma unroll
-    for (int db = 0; db < 8; ++db) {
-      const unsigned char* p0 = v_lds + vfrag + db * 32;
-      const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
-      const s16x4_t a1 =
-          __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * kMVRow));
-      const s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-      oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), pb, oacc[db], 0, 0, 0);
-    }
-  }
-  l_run += __shfl_xor(l_run, 16, 64);
-  l_run += __shfl_xor(l_run, 32, 64);
+      for (int c = 0; c < 4; ++c)
+        qb[c] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const u32x4_t*>(k_lds + col * 256 + (4 * c + quad) * 16));
 
-  // ---- the four quarters merge lane by lane (every wave holds the same (column, dims) per lane): waves 1..3 park
-  //      (O, m, l) in their own LDS region as float[34][64], wave 0 folds them in and writes the partial ----
-  float* mine = reinterpret_cast<float*>(k_lds);
-  if (wave != 0) {
+      auto tile_step = [&](u32x4_t (&kd)[kTL], u32x4_t (&vd)[kTL], int ti) {
+        const bool has_pf = ti + 1 < t_end;                 // tile loads one tile ahead
+        const int pf_blk = has_pf ? tile_block(cur, ti + 1) : 0;
+        if constexpr (KV8) {
+          const int r8 = lane >> 3, c0 = (lane & 7) * 2;
 #pragma unroll
-    for (int db = 0; db < 8; ++db)
+          for (int i = 0; i < kLoads8; ++i) {
+            const int rowi = i * 8 + r8;
+            u32x4_t lo16, hi16;
+            fp8x16_to_bf16(kd[i], &lo16, &hi16);
+            *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((c0 ^ (rowi & 15)) << 4)) = lo16;
+            *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + (((c0 + 1) ^ (rowi & 15)) << 4)) = hi16;
+          }
 #pragma unroll
-      for (int r = 0; r < 4; ++r) mine[(db * 4 + r) * 64 + lane] = oacc[db][r];
-    mine[32 * 64 + lane] = m_run;
-    mine[33 * 64 + lane] = l_run;
-  }
-  __syncthreads();
-  if (wave != 0) return;
+          for (int i = 0; i < kLoads8; ++i) {
+            const int rowi = i * 8 + r8;
+            u32x4_t lo16, hi16;
+            fp8x16_to_bf16(vd[i], &lo16, &hi16);
+            *reinterpret_cast<u32x4_t*>(v_lds + rowi * kMVRow + c0 * 16) = lo16;
+            *reinterpret_cast<u32x4_t*>(v_lds + rowi * kMVRow + (c0 + 1) * 16) = hi16;
+          }
+        } else {
 #pragma unroll
-  for (int w = 1; w < kWaves; ++w) {
-    const float* other = reinterpret_cast<const float*>(smem_raw + w * kMWaveLds);
-    const float mw = other[32 * 64 + lane], lw = other[33 * 64 + lane];
-    const float mn = fmaxf(m_run, mw);
-    const float fa_ = exp2f(m_run - mn), fb_ = exp2f(mw - mn);
-    m_run = mn;
-    l_run = l_run * fa_ + lw * fb_;
+          for (int i = 0; i < kLoads; ++i) {
+            const int rowi = i * 4 + rq;
+            *reinterpret_cast<u32x4_t*>(k_lds + rowi * kMKRow + ((sub ^ (rowi & 15)) << 4)) = kd[i];
+          }
 #pragma unroll
-    for (int db = 0; db < 8; ++db)
+          for (int i = 0; i < kLoads; ++i)
+            *reinterpret_cast<u32x4_t*>(v_lds + (i * 4 + rq) * kMVRow + sub * 16) = vd[i];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_pf) tile_load(kd, vd, cur, pf_blk, ti + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S^T, online softmax (every prefix token precedes every live sequence's new token: no masking), O^T ----
+        f32x4_t sacc[2];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) oacc[db][r] = oacc[db][r] * fa_ + other[(db * 4 + r) * 64 + lane] * fb_;
-  }
-  const int seq = b0 + col / Gv, hd = col % Gv;
-  if (col < P * Gv && seq < batch && ctx[seq] > 0 && member[seq] == gid) {
-    const int64_t pidx = ((int64_t)seq * hq + h * Gv + hd) * slots + (slots - 1);
-    float* dst = part_o + pidx * 128 + 4 * quad;
+        for (int hf = 0; hf < 2; ++hf) {
+          sacc[hf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int db = 0; db < 8; ++db) *reinterpret_cast<f32x4_t*>(dst + 16 * db) = oacc[db];
-    if (quad == 0) {
-      part_ml[pidx * 2] = m_run;
-      part_ml[pidx * 2 + 1] = l_run;
+          for (int c = 0; c < 4; ++c) {
+            const u32x4_t a = *reinterpret_cast<const u32x4_t*>(k_lds + hf * 16 * kMKRow + kfrag[c]);
+            sacc[hf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), qb[c], sacc[hf], 0, 0, 0);
+          }
+        }
+        float mx = kNegBig;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            sacc[hf][rr] *= scale_log2e;
+            mx = fmaxf(mx, sacc[hf][rr]);
+          }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - mn);
+        m_run = mn;
+        float psum = 0.f;
+        bf16x8_t pb;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const float pv = exp2f(sacc[hf][rr] - mn);
+            psum += pv;
+            pb[hf * 4 + rr] = (bf16_t)pv;
+          }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) oacc[db] *= alpha;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) {
+          const unsigned char* p0 = v_lds + vfrag + db * 32;
+          const s16x4_t a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0));
+          const s16x4_t a1 =
+              __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p0 + 16 * kMVRow));
+          const s16x8_t a = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+          oacc[db] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a), pb, oacc[db], 0, 0, 0);
+        }
+      };
+      for (int ti = t_begin; ti < t_end; ++ti) tile_step(kdA, vdA, ti);
+      l_run += __shfl_xor(l_run, 16, 64);
+      l_run += __shfl_xor(l_run, 32, 64);
     }
-  }
+    // ---- the next item: its header arrived long ago; its first tiles are requested HERE, in front of this item's merge, and
+    //      the header of the item after it goes out ----
+    const int live_ctx = ctx_j, live_grp = grp_j;                  // (this item's header: the store mask below)
+    const Item nxt = resolve(item + nblocks, ctx_n, grp_n);
+    ctx_j = ctx_n; grp_j = grp_n;
+    hdr_load(item + 2 * nblocks, ctx_n, grp_n);
+    first_tiles(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    if (gid != 0) {
+      // ---- the four quarters merge lane by lane (every wave holds the same (column, dims) per lane): waves 1..3 park
+      //      (O, m, l) in their own LDS region as float[34][64], wave 0 folds them in and writes the partial ----
+      float* mine = reinterpret_cast<float*>(k_lds);
+      if (wave != 0) {
+#pragma unroll
+        for (int db = 0; db < 8; ++db)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mine[(db * 4 + r) * 64 + lane] = oacc[db][r];
+        mine[32 * 64 + lane] = m_run;
+        mine[33 * 64 + lane] = l_run;
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w) {
+          const float* other = reinterpret_cast<const float*>(smem_raw + w * kMWaveLds);
+          const float mw = other[32 * 64 + lane], lw = other[33 * 64 + lane];
+          const float mn = fmaxf(m_run, mw);
+          const float fa_ = exp2f(m_run - mn), fb_ = exp2f(mw - mn);
+          m_run = mn;
+          l_run = l_run * fa_ + lw * fb_;
+#pragma unroll
+          for (int db = 0; db < 8; ++db)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[db][r] = oacc[db][r] * fa_ + other[(db * 4 + r) * 64 + lane] * fb_;
+        }
+      }
+      __syncthreads();                            // the parked quarters are consumed: the regions are free for the next item
+      const int sj = col / Gv, hd = col % Gv;
+      const int seq = b0 + sj;
+      const int len = __shfl(live_ctx, sj < P ? sj : 0, 64), grp = __shfl(live_grp, sj < P ? sj : 0, 64);
+      if (wave == 0 && col < P * Gv && seq < batch && len > 0 && grp == gid) {
+        const int64_t pidx = ((int64_t)seq * hq + h * Gv + hd) * slots + (slots - 1);
+        float* dst = part_o + pidx * 128 + 4 * quad;
+#pragma unroll
+        for (int db = 0; db < 8; ++db) *reinterpret_cast<f32x4_t*>(dst + 16 * db) = oacc[db];
+        if (quad == 0) {
+          part_ml[pidx * 2] = m_run;
+          part_ml[pidx * 2 + 1] = l_run;
+        }
+      }
+    }
+    cur = nxt;
+  }   // items
+}
+
+// One launch for a step with a shared prefix: workgroups [0, main_blocks) are the stream-K grid the plan was built for,
+// workgroups [main_blocks, gridDim.x) serve the shared-prefix packs (px_split() on the host side decides the division).
+template <bool FUSED, bool KV8, int G, bool SLABS>
+__global__ __launch_bounds__(256, 2) void decode_mfma8_shared_kernel(
+    const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
+    int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
+    int* __restrict__ meta, bf16_t* __restrict__ out, int batch, int hkv, int block_size, int slots,
+    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan, int g_rt, int main_blocks, int group_slots, int px_first) {
+  const int px_blocks = (int)gridDim.x - main_blocks;
+  const int mb = px_first ? (int)blockIdx.x - px_blocks : (int)blockIdx.x;                 // index in the stream-K grid (< 0 or >= main_blocks: a pack workgroup)
+  if (mb >= 0 && mb < main_blocks)
+    mfma8_body<FUSED, KV8, G, SLABS>(q, kc, vc, block_tables, bt_stride, ctx, part_o, part_ml, meta, out, batch, hkv, block_size,
+                                     slots, scale_log2e, fa, plan, g_rt, mb, main_blocks);
+  else
+    prefix_body<FUSED, KV8, G, SLABS>(q, kc, vc, block_tables, bt_stride, ctx, part_o, part_ml, batch, hkv, block_size, slots,
+                                      scale_log2e, fa, plan, g_rt, px_first ? (int)blockIdx.x : mb - main_blocks, px_blocks,
+                                      group_slots);
 }
 
 __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float* __restrict__ part_o,
@@ -1431,7 +1512,7 @@ __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float*
 // one-kv-head shape of Qwen3-32B per rank at TP = 8 — moves 1.2 us from the main kernel into the split merge, which then
 // has twice the partials: 19.1 + 4.5 -> 18.0 + 5.6 us per launch, nothing on the bench shape.
 // profiles/r04_decode_min_tiles_ab.json)
-// (+ 1: the last slot belongs to the shared-prefix pass — decode_prefix_kernel — and is never written by a stream-K wave)
+// (+ 1: the last slot belongs to the shared-prefix pass — prefix_body — and is never written by a stream-K wave)
 inline int stream_slots(int64_t max_context) { return (int)(max_context / (kTile * kMinTilesPerWave)) + 3; }
 
 // LDS and grid of decode_mfma8_kernel — shared by its launcher and by nvl_decode_plan, whose per-wave records are only
@@ -1446,6 +1527,46 @@ inline int64_t mfma8_grid(int64_t batch, int hkv, int64_t max_context, bool plan
   const int64_t max_wg = (max_tiles + kWaves * kMinTilesPerWave - 1) / (kWaves * kMinTilesPerWave);
   if (grid > max_wg) grid = max_wg;
   return grid < 1 ? 1 : grid;
+}
+// A step with a shared prefix (plan built with `groups` > 0 group slots): the launch's workgroups are divided between the
+// stream-K grid (`main_blocks`: what the plan's wave records are made for) and the workgroups that serve the shared-prefix
+// packs (`px_blocks`; decode_mfma8_shared_kernel). One prefix workgroup per kPxItemsPerWg items (an item = one pack x kv head
+// x group slot: a ~4-5 us latency chain, against ~7 us per tile of a stream-K wave's HBM-bound share), at most a third of the
+// resident workgroups. nvl_decode_plan and the launcher both call this: the plan is only valid for `main_blocks`.
+inline int px_items_per_wg() {
+  static const int v = [] {
+    const char* e = getenv("NVL_PX_ITEMS_PER_WG");
+    const int x = e != nullptr ? atoi(e) : 0;
+    return x >= 1 && x <= 64 ? x : 3;
+  }();
+  return v;
+}
+inline int px_first() {
+  static const int v = [] { const char* e = getenv("NVL_PX_FIRST"); return e != nullptr && atoi(e) != 0 ? 1 : 0; }();
+  return v;
+}
+// NVL_PX_SEPARATE=1: the pass as a launch of its own in front of the full stream-K grid (round 5's form, kept for A/B runs)
+inline int px_separate() {
+  static const int v = [] { const char* e = getenv("NVL_PX_SEPARATE"); return e != nullptr && atoi(e) != 0 ? 1 : 0; }();
+  return v;
+}
+inline void px_split(int64_t batch, int hkv, int Gv, int64_t max_context, int groups, int64_t* main_blocks, int64_t* px_blocks) {
+  const int64_t full = mfma8_grid(batch, hkv, max_context, true);
+  const int64_t resident = (int64_t)nvl_device_cu_count() * 2;
+  const int P = 16 / Gv;
+  const int64_t items = ((batch + P - 1) / P) * hkv * groups;
+  if (px_separate()) {
+    *main_blocks = full;
+    *px_blocks = items;
+    return;
+  }
+  int64_t px = (items + px_items_per_wg() - 1) / px_items_per_wg();
+  if (px > resident / 3) px = resident / 3;
+  if (px < 1) px = 1;
+  int64_t mb = full < resident - px ? full : resident - px;
+  if (mb < 1) mb = 1;
+  *main_blocks = mb;
+  *px_blocks = px;
 }
 
 int plan_shadow_prefix(const void* plan);       // group slots of the shared-prefix pass `plan` was built with (0: none; host-side shadow, below)
@@ -1492,30 +1613,38 @@ int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, 
       nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the matrix-core kernel");
       return NVL_ELAUNCH;
     }
-    // ... and for the shared-prefix pass of the same instantiation (69,632 B, above the 64 KiB default): made HERE, with the
-    // plain kernel's — the first launch of an instantiation is an eager warm-up, while the first launch WITH the pass may
+    // ... and for the shared-prefix form of the same instantiation (the stream-K grid + the pack workgroups in one launch):
+    // made HERE, with the plain kernel's — the first launch of an instantiation is an eager warm-up, while the first launch WITH the pass may
     // sit inside a stream capture (the engine captures a bucket's prefix graph when a step first wants it)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_prefix_kernel<FUSED, KV8, G, SLABS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kWaves * kMWaveLds) != hipSuccess) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_shared_kernel<FUSED, KV8, G, SLABS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the shared-prefix kernel");
       return NVL_ELAUNCH;
     }
     attr_set = true;
   }
   NVL_REQUIRE(lds <= 160 * 1024, "nvl_paged_attn_decode: batch=%lld needs %zu B of LDS (> 160 KiB)", (long long)batch, lds);
-  const int64_t grid = mfma8_grid(batch, hkv, max_context, plan != nullptr);
   if (prefix) {
-    // shared-prefix pass first (its partial is in place when the merge runs; it reads q / K / V only, so its order
-    // relative to the stream-K kernel — which appends the new token's K / V behind the prefix — does not matter)
-    const int P = 16 / Gv;
-    const int64_t pgrid = ((batch + P - 1) / P) * hkv;
-    hipLaunchKernelGGL((decode_prefix_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)pgrid, (unsigned)prefix), dim3(256), kWaves * kMWaveLds, s,
-                       (const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, (int)batch,
-                       hkv, block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt);
+    // shared prefix: ONE launch — the stream-K grid the plan was built for, plus the workgroups that serve the packs (they
+    // read q / K / V only and write the partial slot no stream-K wave writes, so nothing orders the two kinds of workgroup;
+    // the merge launch behind sees both)
+    int64_t main_blocks, px_blocks;
+    px_split(batch, hkv, Gv, max_context, prefix, &main_blocks, &px_blocks);
+    const bool separate = px_separate() != 0;
+    hipLaunchKernelGGL((decode_mfma8_shared_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)((separate ? 0 : main_blocks) + px_blocks)),
+                       dim3(256), lds, s, (const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta,
+                       (bf16_t*)out, (int)batch, hkv, block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan,
+                       g_rt, separate ? 0 : (int)main_blocks, prefix, px_first());
+    if (separate)
+      hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)main_blocks), dim3(256), lds, s, (const bf16_t*)q,
+                         (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
+                         block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt);
+  } else {
+    const int64_t grid = mfma8_grid(batch, hkv, max_context, plan != nullptr);
+    hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
+                       (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
+                       block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt);
   }
-  hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
-                     (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
-                     block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt);
   hipLaunchKernelGGL(decode_stream_combine_kernel, dim3((unsigned)(batch * hq)), dim3(128), 0, s, part_o, part_ml,
                      meta, ctx, (bf16_t*)out, hq, hkv, slots, lse, (const PlanHeader*)plan, prefix ? slots - 1 : -1);
   return nvl_check_launch("nvl_paged_attn_decode");
@@ -1862,7 +1991,10 @@ extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int n
   NVL_REQUIRE(max_context > 0, "%s: bad max_context", who);
   NVL_REQUIRE(plan_bytes >= nvl_decode_plan_bytes(), "%s: plan buffer %zu B < required %zu B", who, plan_bytes, nvl_decode_plan_bytes());
   if (batch == 0) return NVL_OK;
-  const int nwaves = (int)mfma8_grid(batch, num_kv_heads, max_context, true) * kWaves;
+  int64_t main_blocks = mfma8_grid(batch, num_kv_heads, max_context, true), px_blocks = 0;
+  if (shared_prefix_blocks != nullptr)      // the stream-K grid of a shared-prefix launch leaves room for the pack workgroups
+    px_split(batch, num_kv_heads, num_q_heads / num_kv_heads, max_context, shared_prefix_groups, &main_blocks, &px_blocks);
+  const int nwaves = (int)main_blocks * kWaves;
   const size_t lds = kWaves * sizeof(int) + (size_t)(batch + 2) * sizeof(int);      // wave sums, tile prefix, shortest row
   static bool attr_done[NVL_MAX_DEVICES] = {};
   bool& attr_set = attr_done[nvl_device_slot()];

@@ -176,7 +176,7 @@ pmcpx)
   rm -rf /tmp/pmc_g4px /tmp/pmc_g4nopx
   (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'decode_' -f csv -d /tmp/pmc_g4px -o replay -- python $REPO/tools/attn_replay.py --fused --reps 1 --hq 32 --hkv 8 --layers 36 --every 8 --workload prefix --pool-blocks 6432 > $OUT/replay_under_pmc_g4_prefix.json 2> $OUT/replay_pmc_g4_prefix.err; echo "pmc G=4 prefix rc=$?")
   python tools/pmc_summary.py /tmp/pmc_g4px $OUT/pmc_fetch_summary_g4_prefix.json > /dev/null
-  python tools/pmc_traffic_update.py $OUT/pmc_fetch_summary_g4_prefix.json $OUT/replay_under_pmc_g4_prefix.json qwen3-8b "decode_prefix_kernel + decode_mfma8_kernel<fused, bf16 KV, G=4>"
+  python tools/pmc_traffic_update.py $OUT/pmc_fetch_summary_g4_prefix.json $OUT/replay_under_pmc_g4_prefix.json qwen3-8b "decode_mfma8_shared_kernel<fused, bf16 KV, G=4>"
   (cd /tmp && timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-include-regex 'decode_' -f csv -d /tmp/pmc_g4nopx -o replay -- python $REPO/tools/attn_replay.py --fused --reps 1 --hq 32 --hkv 8 --layers 36 --every 8 --workload prefix --pool-blocks 6432 --no-shared-prefix > $OUT/replay_under_pmc_g4_prefix_pass_off.json 2> $OUT/replay_pmc_g4_prefix_pass_off.err; echo "pmc G=4 prefix, pass off rc=$?")
   python tools/pmc_summary.py /tmp/pmc_g4nopx $OUT/pmc_fetch_summary_g4_prefix_pass_off.json | tail -8
   cp profiles/pmc_traffic.json $OUT/pmc_traffic.json

@@ -22,7 +22,8 @@ fetch = {r["kernel"]: r for r in rows if r["counter"] == "FETCH_SIZE"}
 # split merge nor the per-step plan — and by far the largest)
 main = max((v for k, v in fetch.items() if "combine" not in k and "plan" not in k and "prefix" not in k), key=lambda v: v["mean"])
 comb = next((v for k, v in fetch.items() if "combine" in k), None)
-# the shared-prefix pass (one more launch per attention call when the label names it): its share of a call's bytes
+# the shared-prefix pass when it is a launch of its own (NVL_PX_SEPARATE=1 runs; label names it): its share of a call's bytes. In
+# the shipped form the packs are workgroups of the main launch (decode_mfma8_shared_kernel: the `main` row)
 pref = next((v for k, v in fetch.items() if "prefix" in k), None) if "prefix" in label else None
 per_launch_kib = main["mean"] + (comb["mean"] if comb else 0.0) + (pref["mean"] * pref["dispatches"] / main["dispatches"] if pref else 0.0)
 hbm = per_launch_kib * 1024 * 2

@@ -1,8 +1,21 @@
+# A/B of the shared-prefix attention on BASELINE config 3 inside ONE build of the library: kernel + engine parity, then
+# bench.py --model qwen3-8b --workload prefix per arm (sep = NVL_PX_SEPARATE=1: the pass as its own launch in front of the full
+# stream-K grid; a number = NVL_PX_ITEMS_PER_WG of the one-launch form)
 set -u
-OUT=gpurun_out/${TAG:-r06v}; mkdir -p $OUT; export TMPDIR=/tmp; REPO=$(pwd)
-timeout 400 python -m pytest tests/test_shared_prefix_gpu.py -q -rf -x > $OUT/pytest_px_kernel.log 2>&1; echo "px kernel rc=$?"; tail -3 $OUT/pytest_px_kernel.log
-for x in ${ARMS:-old new}; do
-  if [ $x = old ]; then export NVL_LIBDIR=$REPO/nano_vllm_amd/lib_probes_b; else unset NVL_LIBDIR; fi
-  (cd /tmp && OMP_NUM_THREADS=8 timeout 400 rocprofv3 --kernel-trace --stats --truncate-kernels -f csv -d /tmp/prof_cfg3_$x -o cfg3 -- python $REPO/bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $REPO/$OUT/cfg3_${x}_under_rocprof.json 2> $REPO/$OUT/cfg3_${x}_prof.err; echo "prof $x rc=$?")
-  f=$(find /tmp/prof_cfg3_$x -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/cfg3_${x}_kernel_stats.csv && grep -E "decode_" $OUT/cfg3_${x}_kernel_stats.csv | cut -c1-20,110-190
-done
+OUT=gpurun_out/${TAG:-r06w}; mkdir -p $OUT; export TMPDIR=/tmp; REPO=$(pwd)
+if [ "${TESTS:-1}" = 1 ]; then
+timeout 400 python -m pytest tests/test_shared_prefix_gpu.py -q -rf -x > $OUT/pytest_px_kernel.log 2>&1; echo "px kernel rc=$?"; tail -3 $OUT/pytest_px_kernel.log | cut -c1-300
+NVL_PX_SEPARATE=1 timeout 400 python -m pytest tests/test_shared_prefix_gpu.py -q -rf -x > $OUT/pytest_px_kernel_sep.log 2>&1; echo "px kernel (separate) rc=$?"; tail -3 $OUT/pytest_px_kernel_sep.log | cut -c1-300
+timeout 500 python -m pytest tests/test_e2e_gpu.py -q -rf -k "shared_system_prompt or two_shared or block_edges or g5" > $OUT/pytest_px_e2e.log 2>&1; echo "px e2e rc=$?"; tail -3 $OUT/pytest_px_e2e.log | cut -c1-300
+fi
+n=0
+for x in ${ARMS:-sep 3 sep 3}; do
+  n=$((n+1))
+  unset NVL_PX_SEPARATE NVL_PX_ITEMS_PER_WG
+  if [ $x = sep ]; then export NVL_PX_SEPARATE=1; else export NVL_PX_ITEMS_PER_WG=$x; fi
+  OMP_NUM_THREADS=8 timeout 300 python bench.py --model qwen3-8b --workload prefix --warmup 1 --steps 1 --no-cpu-baseline --no-extra-configs > $OUT/cfg3_${x}_$n.json 2> $OUT/cfg3_${x}_$n.err
+  python -c "
+import json
+d=json.loads([l for l in open('$OUT/cfg3_${x}_$n.json') if l.startswith('{')][-1])
+r=d['roofline']; print('arm $x:', round(d['value']), 'tok/s; attn', round(r['avg_launch_us'],1), 'us', 'step', d['config']['decode_ms_per_step_by_batch']['ms_per_step'])
+" || tail -5 $OUT/cfg3_${x}_$n.err; done
