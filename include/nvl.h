@@ -243,6 +243,8 @@ int nvl_paged_attn_decode(const void* q, const void* k_cache, const void* v_cach
  *   A plan built with it makes the attention calls that consume it run a SHARED-PREFIX PASS: those blocks are read
  *   once per pack of floor(16 / (Hq/Hkv)) consecutive sequences instead of once per member, and the per-sequence kernel
  *   starts a member behind them; results are merged like any split (same value up to the fp32 summation order).
+ *   (The packs are served by extra workgroups of the SAME attention launch; the plan's per-sequence grid is made that much
+ *   smaller, which is one more reason why a plan is only valid for the calls it was built for.)
  *   The array is read on the device when the plan kernel AND the attention kernels run (graph replays see the current
  *   values; it must stay valid as long as the plan is used, like context_lens). [0] = 0: no shared prefix, the pass
  *   is a no-op. The count is clamped so that the tile holding a member's newest token always stays in that

@@ -113,14 +113,16 @@ struct PlanHeader {          // 48 bytes, followed by nwaves PlanEntry records
   int32_t nwaves, batch, hkv;
   int32_t sh_tiles;          // leading tiles of every MEMBER sequence that the shared-prefix pass computes (0: none)
   const int32_t* member;     // [batch] != 0: the sequence starts with the shared blocks (the caller's array; sh_tiles > 0 only)
-  int64_t pad;
+  int32_t px_groups;         // group slots of the shared-prefix pass (0: a plan without one)
+  int32_t pad;
 };
 static_assert(sizeof(PlanHeader) % 16 == 0, "the wave records behind the header are 16-byte aligned");
 struct __attribute__((aligned(16))) PlanEntry { int32_t b, h, t0, nb; };   // first segment of a wave's share (b < 0: none)
 
 __global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restrict__ ctx, int batch, int hkv, int nwaves,
                                                           PlanHeader* __restrict__ hdr,
-                                                          const int32_t* __restrict__ shared_blocks, int tiles_per_block) {
+                                                          const int32_t* __restrict__ shared_blocks, int tiles_per_block,
+                                                          int px_groups) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   int* wsum = reinterpret_cast<int*>(smem_raw);
   int* pre = wsum + kWaves;
@@ -159,6 +161,7 @@ __global__ __launch_bounds__(256) void decode_plan_kernel(const int32_t* __restr
     hdr->hkv = hkv;
     hdr->sh_tiles = sh;
     hdr->member = member;
+    hdr->px_groups = shared_blocks != nullptr ? px_groups : 0;
     hdr->pad = 0;
   }
   PlanEntry* ent = reinterpret_cast<PlanEntry*>(hdr + 1);
@@ -1108,12 +1111,29 @@ __global__ __launch_bounds__(256, 2) void decode_mfma8_kernel(
 // over its share of the (group slot, pack, kv head) items: the ~19 us latency chain of the separate launch (launch boundary,
 // header -> lengths -> block table -> first tile, LDS merge) now runs UNDER the HBM-bound stream-K shares instead of in front of
 // them, on the same CUs.
+// A wave-uniform pointer / integer kept in VECTOR registers: the pack workgroups' walk holds more uniform state (two items, the
+// header of a third, every argument of the stream-K body) than the 102 scalar registers take, and everything moved here is only
+// ever used in per-lane address arithmetic.
+template <typename T>
+__device__ __forceinline__ T* in_vgprs(T* p) {
+  const unsigned lo = (unsigned)reinterpret_cast<uintptr_t>(p), hi = (unsigned)(reinterpret_cast<uintptr_t>(p) >> 32);
+  unsigned vlo, vhi;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(vlo) : "s"(lo));
+  asm volatile("v_mov_b32 %0, %1" : "=v"(vhi) : "s"(hi));
+  return reinterpret_cast<T*>(((uintptr_t)vhi << 32) | (uintptr_t)vlo);
+}
+__device__ __forceinline__ int in_vgprs(int x) {
+  int v;
+  asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(x));
+  return v;
+}
+
 template <bool FUSED, bool KV8, int G, bool SLABS>
 __device__ __forceinline__ void prefix_body(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
-    const int32_t* __restrict__ block_tables, int64_t bt_stride, const int32_t* __restrict__ ctx,
-    float* __restrict__ part_o, float* __restrict__ part_ml, int batch, int hkv, int block_size, int slots,
-    float scale_log2e, const FusedArgs& fa, const PlanHeader* __restrict__ plan, int g_rt, const int block, const int nblocks,
+    const bf16_t* __restrict__ q_s, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+    const int32_t* __restrict__ block_tables, int64_t bt_stride, const int32_t* __restrict__ ctx_s,
+    float* __restrict__ part_o_s, float* __restrict__ part_ml_s, int batch, int hkv, int block_size, int slots_s,
+    float scale_log2e, const FusedArgs& fa_s, const PlanHeader* __restrict__ plan, int g_rt, const int block, const int nblocks,
     const int group_slots) {
   // a pack fills the 16 MFMA columns with P = floor(16 / G) sequences; columns P G .. 15 (group sizes that do not divide 16)
   // are zero padding. G = 0: runtime group size g_rt, as in decode_mfma8_kernel
@@ -1123,7 +1143,24 @@ __device__ __forceinline__ void prefix_body(
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int sh = plan->sh_tiles;
   if (sh <= 0 || plan->batch != batch || plan->hkv != hkv) return;          // (workgroup-uniform)
-  const int32_t* __restrict__ member = plan->member;
+  const int32_t* member = in_vgprs(plan->member);
+  const bf16_t* q = in_vgprs(q_s);
+  const int32_t* ctx = in_vgprs(ctx_s);
+  float* part_o = in_vgprs(part_o_s);
+  float* part_ml = in_vgprs(part_ml_s);
+  const int slots = in_vgprs(slots_s);
+  // (the fused arguments are parked in vector registers for the whole walk; an item's prologue takes the few it needs as
+  //  scalars back for its own duration — `fa` below)
+  FusedArgs fa_v = fa_s;
+  if constexpr (FUSED) {
+    fa_v.cos_sin = in_vgprs(fa_s.cos_sin);
+    fa_v.q_norm_w = in_vgprs(fa_s.q_norm_w);
+    fa_v.qkv_tok_stride = ((int64_t)in_vgprs((int)(fa_s.qkv_tok_stride >> 32)) << 32) | (unsigned)in_vgprs((int)fa_s.qkv_tok_stride);
+    fa_v.max_pos = ((int64_t)in_vgprs((int)(fa_s.max_pos >> 32)) << 32) | (unsigned)in_vgprs((int)fa_s.max_pos);
+    fa_v.eps = __int_as_float(in_vgprs(__float_as_int(fa_s.eps)));
+    fa_v.qkv_splits = in_vgprs(fa_s.qkv_splits);
+    fa_v.qkv_split_stride = in_vgprs(fa_s.qkv_split_stride);
+  }
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int sub = lane & 15, rq = lane >> 4;      // prologue view: 16 lanes x 8 dims = one row
   const int col = lane & 15, quad = lane >> 4;    // MFMA view: one (sequence, head) column per lane
@@ -1226,11 +1263,19 @@ __device__ __forceinline__ void prefix_body(
     if (gid != 0) {
       // ---- q tile [16 columns][128]: column r = (sequence b0 + r / G, head h G + r % G); rows of dead sequences are zero ----
       {
+        FusedArgs fa = fa_v;
+        if constexpr (FUSED && SLABS) {           // (the slab loop's bound and stride are scalars again, for this prologue only)
+          fa.qkv_splits = __builtin_amdgcn_readfirstlane(fa_v.qkv_splits);
+          fa.qkv_split_stride = __builtin_amdgcn_readfirstlane(fa_v.qkv_split_stride);
+        }
         u32x4_t wq = {0u, 0u, 0u, 0u};
         if constexpr (FUSED) {
           if (fa.q_norm_w != nullptr) wq = *reinterpret_cast<const u32x4_t*>(fa.q_norm_w + sub * 8);
         }
-#pragma unroll
+        // (slab sums / the runtime group size: a rolled loop, as in the stream-K body — four unrolled passes hold more scalars
+        //  than there are)
+        constexpr int kPxUnroll = (SLABS || G == 0) ? 1 : 4;
+#pragma unroll kPxUnroll
         for (int it = 0; it < 4; ++it) {
           const int r = rq + 4 * it;
           const int sj = r / Gv, hd = r % Gv;
@@ -1398,23 +1443,34 @@ __device__ __forceinline__ void prefix_body(
   }   // items
 }
 
-// One launch for a step with a shared prefix: workgroups [0, main_blocks) are the stream-K grid the plan was built for,
-// workgroups [main_blocks, gridDim.x) serve the shared-prefix packs (px_split() on the host side decides the division).
+// One launch for a step with a shared prefix: workgroups [0, main_blocks) are the stream-K grid the plan was built for
+// (main_blocks = plan->nwaves / 4), workgroups [main_blocks, gridDim.x) serve the shared-prefix packs (px_split() on the host side
+// decides the division).
 template <bool FUSED, bool KV8, int G, bool SLABS>
 __global__ __launch_bounds__(256, 2) void decode_mfma8_shared_kernel(
     const bf16_t* __restrict__ q, bf16_t* kc, bf16_t* vc, const int32_t* __restrict__ block_tables,
     int64_t bt_stride, const int32_t* __restrict__ ctx, float* __restrict__ part_o, float* __restrict__ part_ml,
     int* __restrict__ meta, bf16_t* __restrict__ out, int batch, int hkv, int block_size, int slots,
-    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan, int g_rt, int main_blocks, int group_slots, int px_first) {
-  const int px_blocks = (int)gridDim.x - main_blocks;
-  const int mb = px_first ? (int)blockIdx.x - px_blocks : (int)blockIdx.x;                 // index in the stream-K grid (< 0 or >= main_blocks: a pack workgroup)
-  if (mb >= 0 && mb < main_blocks)
+    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan, int g_rt, int main_blocks, int group_slots) {
+  if ((int)blockIdx.x < main_blocks)
     mfma8_body<FUSED, KV8, G, SLABS>(q, kc, vc, block_tables, bt_stride, ctx, part_o, part_ml, meta, out, batch, hkv, block_size,
-                                     slots, scale_log2e, fa, plan, g_rt, mb, main_blocks);
+                                     slots, scale_log2e, fa, plan, g_rt, (int)blockIdx.x, main_blocks);
   else
     prefix_body<FUSED, KV8, G, SLABS>(q, kc, vc, block_tables, bt_stride, ctx, part_o, part_ml, batch, hkv, block_size, slots,
-                                      scale_log2e, fa, plan, g_rt, px_first ? (int)blockIdx.x : mb - main_blocks, px_blocks,
+                                      scale_log2e, fa, plan, g_rt, (int)blockIdx.x - main_blocks, (int)gridDim.x - main_blocks,
                                       group_slots);
+}
+
+// The pack workgroups alone — the instantiations whose stream-K body has no scalar registers to spare for a second body in the
+// same kernel (split-K slab prologue, runtime group size) run the pass as a launch of its own in front of the plain kernel.
+template <bool FUSED, bool KV8, int G, bool SLABS>
+__global__ __launch_bounds__(256, 2) void decode_px_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ kc, const bf16_t* __restrict__ vc,
+    const int32_t* __restrict__ block_tables, int64_t bt_stride, const int32_t* __restrict__ ctx,
+    float* __restrict__ part_o, float* __restrict__ part_ml, int batch, int hkv, int block_size, int slots,
+    float scale_log2e, FusedArgs fa, const PlanHeader* __restrict__ plan, int g_rt) {
+  prefix_body<FUSED, KV8, G, SLABS>(q, kc, vc, block_tables, bt_stride, ctx, part_o, part_ml, batch, hkv, block_size, slots,
+                                    scale_log2e, fa, plan, g_rt, (int)blockIdx.x, (int)gridDim.x, plan->px_groups);
 }
 
 __global__ __launch_bounds__(128) void decode_stream_combine_kernel(const float* __restrict__ part_o,
@@ -1541,21 +1597,12 @@ inline int px_items_per_wg() {
   }();
   return v;
 }
-inline int px_first() {
-  static const int v = [] { const char* e = getenv("NVL_PX_FIRST"); return e != nullptr && atoi(e) != 0 ? 1 : 0; }();
-  return v;
-}
-// NVL_PX_SEPARATE=1: the pass as a launch of its own in front of the full stream-K grid (round 5's form, kept for A/B runs)
-inline int px_separate() {
-  static const int v = [] { const char* e = getenv("NVL_PX_SEPARATE"); return e != nullptr && atoi(e) != 0 ? 1 : 0; }();
-  return v;
-}
 inline void px_split(int64_t batch, int hkv, int Gv, int64_t max_context, int groups, int64_t* main_blocks, int64_t* px_blocks) {
   const int64_t full = mfma8_grid(batch, hkv, max_context, true);
   const int64_t resident = (int64_t)nvl_device_cu_count() * 2;
   const int P = 16 / Gv;
   const int64_t items = ((batch + P - 1) / P) * hkv * groups;
-  if (px_separate()) {
+  if (Gv != 2 && Gv != 4 && Gv != 8) {          // runtime-G instantiation: the pass is a launch of its own, one item per workgroup
     *main_blocks = full;
     *px_blocks = items;
     return;
@@ -1616,8 +1663,10 @@ int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, 
     // ... and for the shared-prefix form of the same instantiation (the stream-K grid + the pack workgroups in one launch):
     // made HERE, with the plain kernel's — the first launch of an instantiation is an eager warm-up, while the first launch WITH the pass may
     // sit inside a stream capture (the engine captures a bucket's prefix graph when a step first wants it)
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_mfma8_shared_kernel<FUSED, KV8, G, SLABS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+    const void* px_kernel;
+    if constexpr (G == 0 || SLABS) px_kernel = reinterpret_cast<const void*>(&decode_px_kernel<FUSED, KV8, G, SLABS>);
+    else px_kernel = reinterpret_cast<const void*>(&decode_mfma8_shared_kernel<FUSED, KV8, G, SLABS>);
+    if (hipFuncSetAttribute(px_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
       nvl_set_error("nvl_paged_attn_decode: cannot reserve LDS for the shared-prefix kernel");
       return NVL_ELAUNCH;
     }
@@ -1630,15 +1679,21 @@ int launch_decode_mfma8_s(const void* q, void* kc, void* vc, const int32_t* bt, 
     // the merge launch behind sees both)
     int64_t main_blocks, px_blocks;
     px_split(batch, hkv, Gv, max_context, prefix, &main_blocks, &px_blocks);
-    const bool separate = px_separate() != 0;
-    hipLaunchKernelGGL((decode_mfma8_shared_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)((separate ? 0 : main_blocks) + px_blocks)),
-                       dim3(256), lds, s, (const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta,
-                       (bf16_t*)out, (int)batch, hkv, block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan,
-                       g_rt, separate ? 0 : (int)main_blocks, prefix, px_first());
-    if (separate)
+    if constexpr (G == 0 || SLABS) {
+      // (two launches: the packs, then the plain kernel on the grid the plan was built for — the full one for a runtime group
+      //  size; a slab-sum launch, which the plan could not know about, keeps the divided grid)
+      hipLaunchKernelGGL((decode_px_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)px_blocks), dim3(256), kWaves * kMWaveLds, s,
+                         (const bf16_t*)q, (const bf16_t*)kc, (const bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, (int)batch, hkv,
+                         block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt);
       hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)main_blocks), dim3(256), lds, s, (const bf16_t*)q,
                          (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out, (int)batch, hkv,
                          block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt);
+    } else {
+      hipLaunchKernelGGL((decode_mfma8_shared_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)(main_blocks + px_blocks)), dim3(256),
+                         lds, s, (const bf16_t*)q, (bf16_t*)kc, (bf16_t*)vc, bt, bt_stride, ctx, part_o, part_ml, meta, (bf16_t*)out,
+                         (int)batch, hkv, block_size, slots, scale * 1.4426950408889634f, fa, (const PlanHeader*)plan, g_rt,
+                         (int)main_blocks, prefix);
+    }
   } else {
     const int64_t grid = mfma8_grid(batch, hkv, max_context, plan != nullptr);
     hipLaunchKernelGGL((decode_mfma8_kernel<FUSED, KV8, G, SLABS>), dim3((unsigned)grid), dim3(256), lds, s, (const bf16_t*)q,
@@ -2008,7 +2063,7 @@ extern "C" int nvl_decode_plan(const int32_t* context_lens, int64_t batch, int n
   }
   hipLaunchKernelGGL(decode_plan_kernel, dim3(1), dim3(256), lds, (hipStream_t)stream, context_lens, (int)batch,
                      num_kv_heads, nwaves, (PlanHeader*)plan, shared_prefix_blocks,
-                     shared_prefix_blocks ? block_size / kTile : 0);
+                     shared_prefix_blocks ? block_size / kTile : 0, shared_prefix_blocks ? shared_prefix_groups : 0);
   const int rc = nvl_check_launch(who);
   if (rc == NVL_OK) plan_shadow_put(plan, batch, num_kv_heads, max_context, shared_prefix_blocks != nullptr ? shared_prefix_groups : 0);   // (a failed launch leaves no record)
   return rc;

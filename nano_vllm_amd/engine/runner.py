@@ -474,19 +474,18 @@ class ModelRunner:
         self.use_plan = os.environ.get("NVL_DECODE_PLAN", "1") != "0"
         self.decode_plan = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
         # shared-prefix attention pass (include/nvl.h, nvl_decode_plan): a decode step in which a group of sequences starts
-        # with the same KV blocks (prefix-cache hits on one system prompt) reads them once per pack of 16 / G rows. It is one
-        # more launch per layer, so a step takes it only when the K/V bytes it saves are worth that (prepare_decode);
+        # with the same KV blocks (prefix-cache hits on one system prompt) reads them once per pack of 16 / G rows. The packs
+        # take workgroups away from the stream-K grid of the same launch (round 5: a launch of their own per layer), so a step
+        # takes the pass only when the K/V bytes it saves are worth that (prepare_decode);
         # the graph of a bucket WITH the pass is captured the first time a step of that bucket wants it.
         # NVL_SHARED_PREFIX=0 switches it off; NVL_SHARED_PREFIX_MIN_MB sets the threshold (saved MB per layer). The
-        # default is the measured break-even (profiles/r05_shared_prefix_crossover.json: config 3's workload at 48 / 96 /
-        # 160 / 256 sequences, 0.6B and 8B shapes: -16 / -3 / +7 / +13 % and -6 / -1 / +2 / +4.5 % tok/s with the pass on;
-        # zero crossing at 145-160 MB): the pass is a ~17 us latency-bound launch per layer and shortens the stream-K
-        # shares, and at small batches L2 / Infinity Cache already absorb most of the repeated reads.
-        # With the opt-in fp8 KV cache the pass is OFF unless NVL_SHARED_PREFIX=1 asks for it: half the bytes to save, the
-        # same latency chain plus the fp8 -> bf16 conversion of every shared tile per pack — config 3's workload on the
-        # 0.6B shapes, 256 sequences: 63.99 k tok/s without vs 60.59 k with the pass (gpurun_out r05z).
-        fp8_kv = cfg.kv_cache_dtype == "fp8"
-        self.share_prefix = (self.use_plan and os.environ.get("NVL_SHARED_PREFIX", "0" if fp8_kv else "1") != "0"
+        # default is the measured break-even (profiles/r06_shared_prefix_crossover.json: config 3's workload at 48 / 96 /
+        # 160 / 256 sequences, 0.6B and 8B shapes: -7 / -4 / +9 / +20 % and -2.5 / -1 / +3.6 / +7 % tok/s with the pass
+        # forced on; zero crossing at 135-165 MB): the packs take workgroups from the stream-K grid and their walk is a
+        # latency chain, and at small batches L2 / Infinity Cache already absorb most of the repeated reads.
+        # The opt-in fp8 KV cache takes the pass under the same rule since the packs moved into the stream-K launch
+        # (256 sequences: 0.6B shapes 69.4 -> 75.7 k tok/s, 8B 19.97 -> 20.55 k; with round 5's separate launch it lost).
+        self.share_prefix = (self.use_plan and os.environ.get("NVL_SHARED_PREFIX", "1") != "0"
                              and ops.decode_attention_shares_prefixes(self.geo["heads"], self.geo["kv_heads"],
                                                                       self.block_size))
         self.share_prefix_min_bytes = float(os.environ.get("NVL_SHARED_PREFIX_MIN_MB", "160")) * 1e6
