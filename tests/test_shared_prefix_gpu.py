@@ -265,6 +265,45 @@ def test_several_shared_prefixes_in_one_step(ops, hq, hkv, slots):
             assert not o1[i].any()
 
 
+@pytest.mark.parametrize("hq,hkv", [(8, 2), (10, 2)])
+def test_a_full_batch_on_the_divided_grid(ops, hq, hkv):
+    """BASELINE config 3's step shape at kernel level: 256 rows, a 512-token prefix shared by all but the first 25 (which
+    hold private copies, block_manager.py:110-120), own suffixes of 16 ... 256 tokens. Large enough that (a) the launch's
+    workgroups are really DIVIDED between the stream-K grid and the pack workgroups (attn_decode.hip: px_split — the small
+    cases above leave the stream-K shares as the plain plan makes them), (b) every pack workgroup walks several (pack, kv
+    head) items one after the other. Hq / Hkv = 4 takes the one-launch form, 5 (runtime group size) the pass as its own
+    launch. Every live row against the oracle (output and LSE), and against the plain launch."""
+    gen = g(77)
+    b, private = 256, tuple(range(25))
+    lens = [512 + int(x) for x in torch.randint(16, 257, (b,), generator=gen)]
+    lens[40], lens[41], lens[255] = 0, 0, 0                                  # graph-padding rows inside and at the end
+    bt, total = _tables(lens, 2, gen, private)
+    kc = torch.randn(total, BS, hkv, 128, generator=gen).to(BF16)           # token-major (the oracle's layout)
+    vc = torch.randn(total, BS, hkv, 128, generator=gen).to(BF16)
+    q = torch.randn(b, hq, 128, generator=gen).to(BF16)
+    ctx = torch.tensor(lens, dtype=torch.int32)
+    scale = 128 ** -0.5
+    o_ref, lse_ref = ref.flash_attn_with_kvcache(q.unsqueeze(1), kc, vc, ctx, bt, scale, return_softmax_lse=True)
+    o_ref = o_ref.squeeze(1)
+    dq, dk, dv = q.cuda(), ref.to_head_major(kc).cuda(), ref.to_head_major(vc).cuda()
+    dctx, dbt = ctx.cuda(), bt.cuda()
+    ws = torch.zeros(ops.paged_attn_decode_workspace_bytes(b, hq, MAX_CTX), dtype=torch.uint8, device="cuda")
+    o0 = ops.paged_attn_decode(dq, dk, dv, dbt, dctx, scale, MAX_CTX, ws, plan=ops.decode_plan(dctx, hq, hkv, MAX_CTX))
+    shp = _shp(2, lens, private)              # (the plan keeps a POINTER to the flags: they must outlive its launches, nvl.h)
+    plan = ops.decode_plan(dctx, hq, hkv, MAX_CTX, shared_prefix=shp, block_size=BS)
+    lse1 = torch.zeros(b, hq, dtype=torch.float32, device="cuda")
+    o1 = ops.paged_attn_decode(dq, dk, dv, dbt, dctx, scale, MAX_CTX, torch.zeros_like(ws), plan=plan, lse=lse1)
+    torch.cuda.synchronize()
+    live = [i for i, n in enumerate(lens) if n > 0]
+    absmax = float(o_ref.float()[live].abs().max())
+    assert float((o1.cpu().float()[live] - o_ref.float()[live]).abs().max()) <= 2e-2 * absmax
+    assert float((lse1.cpu()[live] - lse_ref[live]).abs().max()) <= 2e-3
+    assert float((o1.float() - o0.float()).abs().max()) <= 1e-2 * float(o0.float().abs().max())
+    members = [i for i in live if i not in private]
+    assert not torch.equal(o1[members], o0[members]), "the pass did not change a single bit: did it run?"
+    assert not o1[[40, 41, 255]].any()
+
+
 def test_shared_prefix_count_is_read_when_the_captured_plan_replays(ops):
     """The count lives in device memory and the plan kernel reads it when it RUNS: one captured graph (plan + fused
     attention) serves steps with and without a shared prefix — replayed with the count at 2, at 0 and at 2 again it
