@@ -357,7 +357,18 @@ def with_p2p_fallback(attempt, agree):
 
 
 def _is_latched(ex: BaseException) -> bool:
-    return type(ex).__name__ == "NvlError" and "spin limit" in str(ex)
+    """A latched P2P spin timeout: reported by the communicator's status at exit ("spin limit") or — since the latch travels
+    to the host with every step's ids — raised from inside generate() ("gave up waiting for a peer", engine/runner.py)."""
+    return type(ex).__name__ == "NvlError" and ("spin limit" in str(ex) or "gave up waiting for a peer" in str(ex))
+
+
+def _exit_after_latch(llm) -> None:
+    """Shut an engine down whose pass was aborted by a latched collective: the exit reports the same latch again."""
+    try:
+        llm.exit()
+    except Exception as ex:  # noqa: BLE001
+        if not _is_latched(ex):
+            raise
 
 
 def run_tp_external(args, torch, dist, rank, world, tp):
@@ -381,7 +392,13 @@ def run_tp_external(args, torch, dist, rank, world, tp):
                 return None, True
             return None, False
         llm = LLM(path, **kw)
-        elapsed, prompts, out_lens = timed_passes(args, torch, dist, llm, world, "nccl", sync_group=False)
+        try:
+            elapsed, prompts, out_lens = timed_passes(args, torch, dist, llm, world, "nccl", sync_group=False)
+        except Exception as ex:  # noqa: BLE001 — the latch surfaced inside generate(): no number from this attempt, re-run
+            if not _is_latched(ex):
+                raise
+            _exit_after_latch(llm)
+            return {"value": None, "ms_per_step": None, "config": {"p2p_status": repr(ex)}}, True
         result = base_result(args, tp, 1, world, elapsed, sum(out_lens), llm,
                              f"tp{tp} (one engine, tensor-parallel over {tp} GPUs: xGMI P2P all-reduce "
                              f"{'on' if llm.model_runner.p2p else 'OFF (process group: ' + ('RCCL' if dist.get_backend() == 'nccl' else dist.get_backend()) + ')'})")
@@ -615,7 +632,22 @@ def run_replica(args, torch, dist, rank, world, tp, backend):
     # a prefill step starts on a drained queue and ends with a stream sync: its host wall time is its GPU time
     runner._run_prefill = timed(runner._run_prefill, "prefill_steps_s")
 
-    elapsed, prompts, out_lens = timed_passes(args, torch, dist, llm, world, backend, rec)
+    try:
+        elapsed, prompts, out_lens = timed_passes(args, torch, dist, llm, world, backend, rec)
+    except Exception as ex:  # noqa: BLE001 — a latched P2P collective surfaced inside generate(): re-run over the process group
+        if not (_is_latched(ex) and tp > 1 and os.environ.get("NVL_TP_P2P", "1") != "0"):
+            raise
+        _exit_after_latch(llm)
+        os.environ["NVL_TP_P2P"] = "0"                  # (the engine's workers inherit NVL_* when they are spawned)
+        try:
+            result, pending_cpu = run_replica(args, torch, dist, rank, world, tp, backend)
+        finally:
+            os.environ["NVL_TP_P2P"] = "1"
+        result["tp_p2p_attempt"] = {"value_invalid": None, "ms_per_step": None, "p2p_status": repr(ex),
+                                    "note": "a P2P collective latched a spin timeout inside generate() in this attempt; "
+                                            "`value` is the re-run with NVL_TP_P2P=0"}
+        result["config"]["parallelism"] += " [fallback after a latched P2P spin timeout]"
+        return result, pending_cpu
     total_out = sum(out_lens)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")

@@ -514,6 +514,24 @@ def test_bench_tp_run_falls_back_to_the_process_group_and_never_reports_null():
         pass
     assert bench._is_latched(NvlError("nvl error -2: nvl_allreduce: a peer did not arrive within the spin limit"))
     assert not bench._is_latched(NvlError("something else")) and not bench._is_latched(RuntimeError("spin limit"))
+    # the latch as step() / generate() raise it since round 6 (engine/runner.py: _raise_if_collective_timed_out) — the wording
+    # is taken from the runner's source, so that a rephrasing there cannot silently disable the re-run
+    import inspect
+    from nano_vllm_amd.engine import runner as runner_mod
+    src = inspect.getsource(runner_mod.ModelRunner._raise_if_collective_timed_out)
+    assert "gave up waiting for a peer" in src
+    assert bench._is_latched(NvlError("a tensor-parallel P2P collective gave up waiting for a peer during a decode step: ..."))
+    # ... and an attempt aborted INSIDE generate() (no number at all) still ends in the re-run's value
+    calls.clear()
+
+    def aborted(p2p):
+        calls.append(p2p)
+        if p2p:
+            return {"value": None, "ms_per_step": None, "config": {"p2p_status": "NvlError('... gave up waiting for a peer ...')"}}, True
+        return {"value": 80.0, "ms_per_step": 1.0, "config": {"parallelism": "tp2", "p2p_status": "n/a (process group)"}}, False
+    r = bench.with_p2p_fallback(aborted, agree=lambda f: f)
+    assert calls == [True, False] and r["value"] == 80.0 and r["tp_p2p_attempt"]["value_invalid"] is None
+    assert "gave up waiting" in r["tp_p2p_attempt"]["p2p_status"]
 
 
 def test_bench_line_stays_compact(monkeypatch, tmp_path):
