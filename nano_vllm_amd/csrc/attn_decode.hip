@@ -1586,14 +1586,14 @@ inline int64_t mfma8_grid(int64_t batch, int hkv, int64_t max_context, bool plan
 }
 // A step with a shared prefix (plan built with `groups` > 0 group slots): the launch's workgroups are divided between the
 // stream-K grid (`main_blocks`: what the plan's wave records are made for) and the workgroups that serve the shared-prefix
-// packs (`px_blocks`; decode_mfma8_shared_kernel). One prefix workgroup per kPxItemsPerWg items (an item = one pack x kv head
+// packs (`px_blocks`; decode_mfma8_shared_kernel). One prefix workgroup per px_items_per_wg() = 2 items (an item = one pack x kv head
 // x group slot: a ~4-5 us latency chain, against ~7 us per tile of a stream-K wave's HBM-bound share), at most a third of the
 // resident workgroups. nvl_decode_plan and the launcher both call this: the plan is only valid for `main_blocks`.
 inline int px_items_per_wg() {
   static const int v = [] {
     const char* e = getenv("NVL_PX_ITEMS_PER_WG");
     const int x = e != nullptr ? atoi(e) : 0;
-    return x >= 1 && x <= 64 ? x : 3;
+    return x >= 1 && x <= 64 ? x : 2;
   }();
   return v;
 }
