@@ -4,15 +4,15 @@ Plays the role of the reference's `utils/context.py:6-27` — the op-level drop-
 the runner publishes per-step metadata with `set_context(...)`, `Attention.forward` and
 `ParallelLMHead.forward` read it with `get_context()`, and `reset_context()` clears it. Field
 names and the positional order of `set_context` follow the reference so reference-style
-callers work unchanged; three extra fields carry what the HIP decode kernel needs (its split-KV
-workspace, the static `max_context` bound that makes the launch hipGraph-safe, and the per-step work
-plan shared by every layer's launch — ops.decode_plan).
+callers work unchanged; four extra fields carry what the HIP decode kernel needs (its split-KV
+workspace, the static `max_context` bound that makes the launch hipGraph-safe, the per-step work
+plan shared by every layer's launch — ops.decode_plan — and whether that plan carries a shared prefix).
 """
 from __future__ import annotations
 
 _FIELDS = ("is_prefill", "cu_seqlens_q", "cu_seqlens_k", "max_seqlen_q", "max_seqlen_k", "slot_mapping",
-           "context_lens", "block_tables", "decode_workspace", "max_context", "decode_plan")
-_DEFAULTS = (False, None, None, 0, 0, None, None, None, None, 0, None)
+           "context_lens", "block_tables", "decode_workspace", "max_context", "decode_plan", "shared_prefix")
+_DEFAULTS = (False, None, None, 0, 0, None, None, None, None, 0, None, False)
 
 
 class Context:
@@ -40,7 +40,7 @@ def get_context() -> Context:
 
 def set_context(*args, **kwargs) -> None:
     """set_context(is_prefill, cu_seqlens_q, cu_seqlens_k, max_seqlen_q, max_seqlen_k,
-    slot_mapping, context_lens, block_tables[, decode_workspace, max_context, decode_plan])"""
+    slot_mapping, context_lens, block_tables[, decode_workspace, max_context, decode_plan, shared_prefix])"""
     _Holder.current = Context(*args, **kwargs)
 
 

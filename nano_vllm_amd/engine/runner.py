@@ -479,16 +479,18 @@ class ModelRunner:
         # takes the pass only when the K/V bytes it saves are worth that (prepare_decode);
         # the graph of a bucket WITH the pass is captured the first time a step of that bucket wants it.
         # NVL_SHARED_PREFIX=0 switches it off; NVL_SHARED_PREFIX_MIN_MB sets the threshold (saved MB per layer). The
-        # default is the measured break-even (profiles/r06_shared_prefix_crossover.json: config 3's workload at 48 / 96 /
-        # 160 / 256 sequences, 0.6B and 8B shapes: -7 / -4 / +9 / +20 % and -2.5 / -1 / +3.6 / +7 % tok/s with the pass
-        # forced on; zero crossing at 135-165 MB): the packs take workgroups from the stream-K grid and their walk is a
-        # latency chain, and at small batches L2 / Infinity Cache already absorb most of the repeated reads.
+        # default sits under the smallest saving measured to pay in the final form (two items per pack workgroup, bf16 qkv
+        # on shared-prefix steps — profiles/r06_shared_prefix_engine_check.json: config 3's workload on the 8B shapes at
+        # 96 / 128 / 160 / 256 sequences +3.5 / +5.3 / +5.6 / +6.8 % tok/s with the pass forced on, 111 MB saved at 96;
+        # r06_shared_prefix_items_per_wg.json: 0.6B shapes +9 % at 96 sequences = 130 MB) and above the ones measured to lose
+        # (17-45 MB: one-kv-head rank shapes, 48 sequences): the packs take workgroups from the stream-K grid and their
+        # walk is a latency chain, and at small batches L2 / Infinity Cache already absorb most of the repeated reads.
         # The opt-in fp8 KV cache takes the pass under the same rule since the packs moved into the stream-K launch
         # (256 sequences: 0.6B shapes 69.4 -> 75.7 k tok/s, 8B 19.97 -> 20.55 k; with round 5's separate launch it lost).
         self.share_prefix = (self.use_plan and os.environ.get("NVL_SHARED_PREFIX", "1") != "0"
                              and ops.decode_attention_shares_prefixes(self.geo["heads"], self.geo["kv_heads"],
                                                                       self.block_size))
-        self.share_prefix_min_bytes = float(os.environ.get("NVL_SHARED_PREFIX_MIN_MB", "160")) * 1e6
+        self.share_prefix_min_bytes = float(os.environ.get("NVL_SHARED_PREFIX_MIN_MB", "100")) * 1e6
         self.decode_plan_px = torch.zeros(ops.decode_plan_bytes(), dtype=torch.uint8, device=self.device)
         self.graphs_px: dict[tuple, torch.cuda.CUDAGraph] = {}      # (bucket, group slots) -> graph with the pass
         self.prefix_steps = 0                # decode steps that ran the shared-prefix pass (reporting)
@@ -696,7 +698,7 @@ class ModelRunner:
                             prefix_groups=max(prefix, 1))
         set_context(False, slot_mapping=t["slots"][r0:r1], context_lens=t["ctx"][r0:r1],
                     block_tables=t["bt"][r0:r1], decode_workspace=ws, max_context=self.config.max_model_len,
-                    decode_plan=plan)
+                    decode_plan=plan, shared_prefix=bool(prefix) and plan is not None)
         hidden = self.model(t["ids"][r0:r1], t["pos"][r0:r1])
         self._sample(hidden, t["temps"][r0:r1], self.tokens_dev[r0:r1], t["rng"][:1], sampler, t["rkey"][r0:r1])
         reset_context()

@@ -48,7 +48,11 @@ class Qwen3Attention(nn.Module):
             self.k_norm = RMSNorm(self.head_dim, eps=self.eps)
 
     def forward(self, positions: torch.Tensor, hidden_states: torch.Tensor) -> torch.Tensor:
-        if self.attn.fuses_decode_step(get_context()):
+        ctx = get_context()
+        # (a step whose plan carries a shared prefix takes bf16 qkv: the attention kernel that also serves the shared-prefix packs
+        #  in the SAME launch has no scalar registers left for the slab-sum prologue — attn_decode.hip — and with slabs the pass
+        #  would be a launch of its own on a divided grid)
+        if self.attn.fuses_decode_step(ctx) and not ctx.shared_prefix:
             qkv = self.qkv_proj.forward_for_fused_decode(hidden_states)      # bf16 [N, out], or fp32 split-K slabs
         else:
             qkv = self.qkv_proj(hidden_states)
